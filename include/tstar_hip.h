@@ -1,0 +1,125 @@
+/* tstar_hip.h -- C ABI of libtstar_hip.so: the MI355X (gfx950) implementation of the
+ * T* keyframe-search hot path.
+ *
+ * The reference (mll-lab-nu/TStar) has NO native plug-in ABI: its plug-in surface is two
+ * duck-typed Python classes, HeuristicInterface/OWLInterface
+ * (TStar/interface_heuristic.py:28-37, 200-280) and TStarSearcher
+ * (TStar/interface_searcher.py:14-538).  tstar_amd/ keeps that Python surface and binds
+ * the entry points below with ctypes (tstar_amd/_lib.py); INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.  Each entry point names the reference
+ * code it replaces.
+ *
+ * Conventions
+ *   - plain C types only; "d_" pointers are DEVICE pointers (HBM) owned by the caller,
+ *     "h_" pointers are host pointers; nothing is retained past the call unless stated.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     enqueued on it; no entry point synchronises unless stated.
+ *   - return value 0 = OK; otherwise an error code (TSTAR_ERR_*), with a human-readable
+ *     message from tstar_last_error() (thread-local).
+ *   - integer/byte outputs are bit-exact restatements of the reference arithmetic;
+ *     floating-point outputs match the CPU oracle within 1e-3 (observed ~1e-6).
+ */
+#ifndef TSTAR_HIP_H
+#define TSTAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSTAR_OK 0
+#define TSTAR_ERR_ARG 1
+#define TSTAR_ERR_HIP 2
+#define TSTAR_ERR_STATE 3
+
+#define TSTAR_OWL_NPATCH 576   /* 24 x 24 patches of a 768 x 768 detector image */
+#define TSTAR_OWL_QDIM 512
+#define TSTAR_OWL_TEXT_LEN 16
+#define TSTAR_OWL_MAX_QUERIES 32
+
+const char* tstar_last_error(void);
+int tstar_abi_version(void);
+/* number of float32 values expected in the vision / text weight blobs (layout:
+ * tstar_amd/weights.py vision_spec()/text_spec(), mirrored in csrc/owl_weights.h) */
+size_t tstar_owl_vision_blob_floats(void);
+size_t tstar_owl_text_blob_floats(void);
+
+/* ------------------------------------------------------------------ detector (D-rows) */
+typedef struct tstar_owl tstar_owl;
+
+/* Replaces OWLInterface.__init__/load_model_and_tokenizer + model.to(device)
+ * (interface_heuristic.py:201-210).  Copies the float32 blobs to HBM and allocates the
+ * activation workspace for `max_batch` detector images per pass (larger batches are
+ * processed in chunks).  h_text_blob may be NULL (then only tstar_owl_set_query_embeds
+ * can install queries).  h_norm_lut: 3*256 float32, the rescale+normalise value of every
+ * (channel, u8) pair, computed by the host with the reference's arithmetic
+ * (HF image_transforms.py rescale/normalize via image_processing_pil_owlvit.py). */
+int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision,
+                     const float* h_text_blob, size_t n_text, const float* h_norm_lut, int max_batch);
+int tstar_owl_destroy(tstar_owl* h);
+
+/* Replaces the text half of processor(...)+model(...) that the reference recomputes on every
+ * detector call (interface_heuristic.py:234,239 -> HF modeling_owlvit.py:945-958, 631-663):
+ * runs the CLIP text tower once for Q queries (ids/mask int32 [Q,16]) and keeps the
+ * L2-normalised query embeddings resident.  h_class_weight [Q] = object2weight of each
+ * query's name (interface_searcher.py:88-91,136).  Synchronises `stream`. */
+int tstar_owl_set_queries(tstar_owl* h, const int32_t* h_input_ids, const int32_t* h_attention_mask,
+                          const float* h_class_weight, int Q, void* stream);
+/* Same, from precomputed L2-normalised embeddings float32 [Q,512] and query mask u8 [Q]. */
+int tstar_owl_set_query_embeds(tstar_owl* h, const float* h_query_embeds, const uint8_t* h_query_mask,
+                               const float* h_class_weight, int Q, void* stream);
+/* Copies the resident (L2-normalised, pre-class-head) query embeddings float32 [Q,512] to the host. */
+int tstar_owl_get_query_embeds(tstar_owl* h, float* h_out, int Q, void* stream);
+
+/* Replaces OWLInterface.inference_detector (interface_heuristic.py:232-246: HF preprocess,
+ * both towers' forward, post_process_grounded_object_detection(threshold=0.005)) AND the
+ * detection->grid-cell loop of TStarSearcher.imageGridScoreFunction
+ * (interface_searcher.py:129-150) for B images of identical size in one call.
+ *   d_images      u8  [B,H,W,3] RGB (the grid image, or a verification frame)
+ *   d_scores      f32 [B,576]   sigmoid(max_q logit)            (dense: not thresholded)
+ *   d_labels      i32 [B,576]   argmax_q logit
+ *   d_boxes_xyxy  f32 [B,576,4] pixels of the passed image
+ *   d_cell_conf   f64 [B,rows*cols]  max over detections with score > 0.005 of
+ *                                    score * class_weight[label], row-major cells; 0 if none
+ *   d_cell_mask   u32 [B,rows*cols]  bit q set <=> a kept detection with label q fell in the cell
+ *   d_n_kept      i32 [B]       number of detections with score > 0.005 (may be NULL)
+ *   d_logits      f32 [B,576,Q] raw logits (may be NULL)
+ *   d_boxes_cxcywh f32 [B,576,4] pred_boxes (may be NULL)
+ */
+int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
+                    float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
+                    uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits, float* d_boxes_cxcywh, void* stream);
+
+/* Diagnostics for parity tests: the preprocessed 768x768 u8 image of the LAST chunk's image 0
+ * (after bicubic) and its patch-embed A operand can be read back. */
+int tstar_owl_debug_preprocess(tstar_owl* h, const uint8_t* d_images, int B, int H, int W,
+                               uint8_t* d_out_u8 /* [B,768,768,3] */, float* d_out_patches /* [B*576,3072] */,
+                               void* stream);
+
+/* ------------------------------------------------------------------ ingest (S1-S3, S8) */
+/* Replaces read_frame_batch + cv2.resize(800x380) + create_image_grid's cv2.resize(200x95) +
+ * hstack/vstack (interface_searcher.py:157-169, 362, 186-188): gathers rows*cols frames by index
+ * from a resident decoded video u8 [N,H,W,3] and writes the grid image u8 [rows*95, cols*200, 3]. */
+int tstar_frames_to_grid(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx,
+                         int grid_rows, int grid_cols, uint8_t* d_grid, void* stream);
+/* Replaces read_frame_batch + cv2.resize (interface_searcher.py:402-403; any target size):
+ * out u8 [n,out_h,out_w,3]. */
+int tstar_frames_resize(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n,
+                        int out_w, int out_h, uint8_t* d_out, void* stream);
+
+/* ------------------------------------------------------------------ kernel-level diagnostics
+ * (used by tests/ and bench.py to check and time individual kernels) */
+/* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual); act: 0 none, 1 quick-gelu, 2 gelu(erf) */
+int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
+                   int M, int N, int K, int act, void* stream);
+int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream);
+/* qkv [B*T, 3*heads*64] -> out [B*T, heads*64]; mode 0 full, 1 causal + key mask u8 [B,T] */
+int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode,
+                        const uint8_t* d_key_mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSTAR_HIP_H */

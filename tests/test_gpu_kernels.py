@@ -1,0 +1,160 @@
+"""Kernel-level parity: each HIP kernel (through the C ABI) vs a plain torch fp32 CPU
+statement of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tstar_amd import _lib
+    return _lib.load()
+
+
+def _check(rc):
+    from tstar_amd import _lib
+    _lib.check(rc)
+
+
+@pytest.mark.parametrize("M,N,K", [(577, 768, 768), (128, 128, 32), (1, 128, 64), (1154, 2304, 768),
+                                   (1000, 768, 3072), (64, 512, 512)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_bias_act(lib, M, N, K, act):
+    g = torch.Generator().manual_seed(M * 7 + N + K + act)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    ref = F.linear(A, W, b)
+    if act == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    dA, dW, db = A.cuda(), W.cuda(), b.cuda()
+    dC = torch.full((M, N), float("nan"), device="cuda")
+    _check(lib.tstar_gemm_f32(dA.data_ptr(), dW.data_ptr(), dC.data_ptr(), db.data_ptr(), None, M, N, K, act,
+                              torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    err = (dC.cpu() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_gemm_asymmetric_identity(lib):
+    """A = I against an asymmetric W: catches row/col swaps in the C/D layout."""
+    N = K = 128
+    A = torch.eye(K)
+    W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 1013) / 7.0
+    dC = torch.empty((K, N), device="cuda")
+    _check(lib.tstar_gemm_f32(A.cuda().data_ptr(), W.cuda().data_ptr(), dC.data_ptr(), None, None, K, N, K, 0,
+                              torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(dC.cpu(), W.t().contiguous())
+
+
+def test_gemm_residual_inplace(lib):
+    M, N, K = 300, 768, 3072
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    X = torch.randn(M, N, generator=g)
+    ref = X + F.linear(A, W, b)
+    dX = X.cuda()
+    _check(lib.tstar_gemm_f32(A.cuda().data_ptr(), W.cuda().data_ptr(), dX.data_ptr(), b.cuda().data_ptr(),
+                              dX.data_ptr(), M, N, K, 0, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert (dX.cpu() - ref).abs().max().item() < 5e-5
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    from tstar_amd import _lib
+    d = torch.zeros(256 * 256, device="cuda")
+    rc = lib.tstar_gemm_f32(d.data_ptr(), d.data_ptr(), d.data_ptr(), None, None, 16, 100, 32, 0, None)
+    assert rc == 1 and b"multiple of 128" in lib.tstar_last_error()
+    with pytest.raises(_lib.TStarHipError):
+        _lib.check(rc)
+
+
+@pytest.mark.parametrize("rows,D", [(577, 768), (5, 768), (64, 512), (1, 512)])
+def test_layernorm(lib, rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g) * 3 + 0.5
+    w = torch.randn(D, generator=g)
+    b = torch.randn(D, generator=g)
+    ref = F.layer_norm(x, (D,), w, b, 1e-5)
+    dy = torch.empty((rows, D), device="cuda")
+    _check(lib.tstar_layernorm_f32(x.cuda().data_ptr(), dy.data_ptr(), w.cuda().data_ptr(), b.cuda().data_ptr(),
+                                   rows, D, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert (dy.cpu() - ref).abs().max().item() < 1e-5
+
+
+def _attn_ref(qkv, B, T, heads, mask=None):
+    D = heads * 64
+    q, k, v = qkv.view(B, T, 3 * D).split(D, dim=-1)
+    q = q.view(B, T, heads, 64).transpose(1, 2)
+    k = k.view(B, T, heads, 64).transpose(1, 2)
+    v = v.view(B, T, heads, 64).transpose(1, 2)
+    att = torch.matmul(q, k.transpose(2, 3)) * 0.125
+    if mask is not None:
+        att = att + mask
+    att = torch.softmax(att, dim=-1)
+    return torch.matmul(att, v).transpose(1, 2).reshape(B * T, D)
+
+
+@pytest.mark.parametrize("B,T,heads", [(1, 577, 12), (2, 577, 12), (3, 16, 8), (1, 33, 2), (1, 128, 1), (1, 1, 1)])
+def test_attention_full(lib, B, T, heads):
+    g = torch.Generator().manual_seed(B * 1000 + T + heads)
+    D = heads * 64
+    qkv = torch.randn(B * T, 3 * D, generator=g)
+    ref = _attn_ref(qkv, B, T, heads)
+    out = torch.full((B * T, D), float("nan"), device="cuda")
+    _check(lib.tstar_attention_f32(qkv.cuda().data_ptr(), out.data_ptr(), B, T, heads, 0, None,
+                                   torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+def test_attention_spiked_scores(lib):
+    """Force large online-softmax rescales: one key dominates late in the sequence."""
+    B, T, heads = 1, 577, 2
+    g = torch.Generator().manual_seed(11)
+    D = heads * 64
+    qkv = torch.randn(B * T, 3 * D, generator=g)
+    qkv[500, D:2 * D] *= 40.0        # huge key late -> max jumps at key block 15
+    qkv[3, D:2 * D] *= 25.0          # and an early big one
+    ref = _attn_ref(qkv, B, T, heads)
+    out = torch.empty((B * T, D), device="cuda")
+    _check(lib.tstar_attention_f32(qkv.cuda().data_ptr(), out.data_ptr(), B, T, heads, 0, None,
+                                   torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert (out.cpu() - ref).abs().max().item() < 5e-5
+
+
+def test_attention_causal_padded(lib):
+    B, T, heads = 4, 16, 8
+    g = torch.Generator().manual_seed(5)
+    D = heads * 64
+    qkv = torch.randn(B * T, 3 * D, generator=g)
+    lens = [3, 4, 16, 2]
+    km = torch.zeros(B, T, dtype=torch.uint8)
+    for i, n in enumerate(lens):
+        km[i, :n] = 1
+    neg = torch.finfo(torch.float32).min
+    causal = torch.full((T, T), neg).triu(1)
+    pad = torch.zeros(B, 1, 1, T).masked_fill(km.view(B, 1, 1, T) == 0, neg)
+    mask = (causal.view(1, 1, T, T) + pad).clamp_min(neg)
+    ref = _attn_ref(qkv, B, T, heads, mask)
+    out = torch.empty((B * T, D), device="cuda")
+    _check(lib.tstar_attention_f32(qkv.cuda().data_ptr(), out.data_ptr(), B, T, heads, 1, km.cuda().data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    o = out.cpu().view(B, T, D)
+    r = ref.view(B, T, D)
+    # rows whose own position is padding attend to nothing valid beyond the causal prefix in HF
+    # (softmax over all-min rows is uniform); only the non-padded query rows feed the pooled output.
+    for i, n in enumerate(lens):
+        assert (o[i, :n] - r[i, :n]).abs().max().item() < 2e-5

@@ -1,0 +1,80 @@
+"""ctypes binding of libtstar_hip.so (include/tstar_hip.h).
+
+There is NO CPU fallback: importing this module without the built library, or
+calling a compute entry point without a HIP device, raises.  Build with
+``python -m tstar_amd.build`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtstar_hip.so")
+
+
+class TStarHipError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/tstar_hip.h
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_fp = C.POINTER(C.c_float)
+SIGNATURES = {
+    "tstar_last_error": (C.c_char_p, []),
+    "tstar_abi_version": (_i, []),
+    "tstar_owl_vision_blob_floats": (_sz, []),
+    "tstar_owl_text_blob_floats": (_sz, []),
+    "tstar_owl_create": (_i, [C.POINTER(_vp), _vp, _sz, _vp, _sz, _vp, _i]),
+    "tstar_owl_destroy": (_i, [_vp]),
+    "tstar_owl_set_queries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "tstar_owl_set_query_embeds": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "tstar_owl_get_query_embeds": (_i, [_vp, _vp, _i, _vp]),
+    "tstar_owl_score": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tstar_owl_debug_preprocess": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "tstar_frames_to_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "tstar_frames_resize": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "tstar_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tstar_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "tstar_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library (once) and bind every declared symbol; fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise TStarHipError(
+            f"{LIB_PATH} is missing: build it with `python -m tstar_amd.build` "
+            "(hipcc --offload-arch=gfx950). tstar_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().tstar_last_error()
+        raise TStarHipError(f"{what or 'tstar_hip'} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,189 @@
+// Flash-style fp32 multi-head self-attention on the CDNA4 matrix cores, head_dim 64.
+//
+// Replaces OwlViTAttention.forward (HF modeling_owlvit.py:428-459; eager math
+// :377-402: softmax(Q K^T / 8 + mask) V) for both towers: vision T=577 / 12
+// heads (no mask) and text T=16 / 8 heads (causal + key-padding mask,
+// modeling_owlvit.py:631-663).  Input is the fused QKV projection
+// [B*T, 3*D] (q | k | v), output [B*T, D] ready for out_proj.
+//
+// Mapping (wave64, v_mfma_f32_32x32x2_f32, exact f32):
+//  * block = 4 waves = 128 query rows of one (image, head); wave w owns 32 rows.
+//  * scores are computed TRANSPOSED, S^T = K Q^T (A = K tile from LDS, B = Q
+//    fragment held in 32 VGPRs for the whole kernel, pre-scaled by
+//    log2(e)/8).  In the 32x32 C/D layout a lane then owns ONE query
+//    (column lane&31) and 16 keys ((r&3)+8(r>>2)+4(lane>>5)): the row max / row
+//    sum are 15 in-lane ops + one cross-half exchange, and the probabilities
+//    are already in B-operand layout for O^T = V^T P^T -- no LDS round trip,
+//    no permutes.  O^T columns are queries too, so the online-softmax rescale is
+//    lane-local.
+//  * K/V tiles (32 keys) are staged global -> VGPR -> LDS, double-buffered, one
+//    barrier per tile; K rows padded to 68 floats (conflict-free ds_read_b128),
+//    V read as ds_read_b32 rows (two 32-lane halves never conflict).
+#include "common.h"
+#include "kernels.h"
+#include <math.h>
+
+namespace tstar {
+
+constexpr int HD = 64, KB = 32, K_LD = HD + 4;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            int T, int heads, int qtiles,
+                                                            const uint8_t* __restrict__ key_mask) {
+    __shared__ __attribute__((aligned(16))) float Ks[2][KB][K_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[2][KB][HD];
+
+    const int D = heads * HD, D3 = 3 * D;
+    int bid = blockIdx.x;
+    const int qt = bid % qtiles; bid /= qtiles;
+    const int head = bid % heads;
+    const int b = bid / heads;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const size_t rowbase = (size_t)b * T;
+
+    // ---- Q fragment (B operand): lane holds Q[q][8c + 4h .. +3], c = 0..7, scaled by log2e/8
+    const int q = qt * 128 + wave * 32 + l31;
+    const int qc = q < T ? q : T - 1;
+    const bool wave_active = (qt * 128 + wave * 32) < T;
+    f32x4 qf[8];
+    {
+        const float* qp = qkv + (rowbase + qc) * D3 + head * HD + 4 * h;
+        const float sc = 0.125f * 1.44269504088896340736f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            qf[c] = *reinterpret_cast<const f32x4*>(qp + 8 * c);
+            qf[c] *= sc;
+        }
+    }
+
+    // ---- staging assignment for K/V tiles: thread -> rows (t>>4), (t>>4)+16; float4 column t&15
+    const int f4 = t & 15, sr = t >> 4;
+    const float* kbase = qkv + D + head * HD + f4 * 4;
+    const float* vbase = qkv + 2 * D + head * HD + f4 * 4;
+    auto krow = [&](int key) { return (rowbase + (key < T ? key : T - 1)) * D3; };
+
+    const int nkb = (T + KB - 1) / KB;
+    f32x4 rk[2], rv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        size_t ro = krow(sr + 16 * i);
+        rk[i] = *reinterpret_cast<const f32x4*>(kbase + ro);
+        rv[i] = *reinterpret_cast<const f32x4*>(vbase + ro);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<f32x4*>(&Ks[0][sr + 16 * i][f4 * 4]) = rk[i];
+        *reinterpret_cast<f32x4*>(&Vs[0][sr + 16 * i][f4 * 4]) = rv[i];
+    }
+    __syncthreads();
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int cur = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const bool more = kb + 1 < nkb;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                size_t ro = krow((kb + 1) * KB + sr + 16 * i);
+                rk[i] = *reinterpret_cast<const f32x4*>(kbase + ro);
+                rv[i] = *reinterpret_cast<const f32x4*>(vbase + ro);
+            }
+        }
+        if (wave_active) {
+            // S^T[key][q] = sum_d K[key][d] * Q[q][d]
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const float* kp = &Ks[cur][l31][4 * h];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                f32x4 ka = *reinterpret_cast<const f32x4*>(kp + 8 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[c][e], s, 0, 0, 0);
+            }
+            // masks + block max
+            const int key0 = kb * KB + 4 * h;
+            float mb = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2);
+                bool ok = key < T;
+                if (MODE == 1) ok = ok && key <= q && key_mask[(size_t)b * T + (key < T ? key : 0)] != 0;
+                s[r] = ok ? s[r] : -INFINITY;
+                mb = fmaxf(mb, s[r]);
+            }
+            mb = fmaxf(mb, __shfl_xor(mb, 32));
+            const float m_new = fmaxf(m_run, mb);
+            // m_new is finite as soon as one key of this or an earlier block is valid
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = exp2f(m_run - m_use);     // exp2(-inf) = 0 on the first block
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = exp2f(s[r] - m_use);
+                ps += s[r];
+            }
+            ps += __shfl_xor(ps, 32);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            // O^T[d][q] += sum_key V[key][d] * P[q][key]
+            const float* vp = &Vs[cur][4 * h][l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = (r & 3) + 8 * (r >> 2);
+                const float v0 = vp[kr * HD];
+                const float v1 = vp[kr * HD + 32];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<f32x4*>(&Ks[cur ^ 1][sr + 16 * i][f4 * 4]) = rk[i];
+                *reinterpret_cast<f32x4*>(&Vs[cur ^ 1][sr + 16 * i][f4 * 4]) = rv[i];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (q < T) {
+        const float inv = 1.0f / l_run;
+        float* op = out + (rowbase + q) * D + head * HD + 4 * h;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = o0[g4 * 4 + e] * inv; c[e] = o1[g4 * 4 + e] * inv; }
+            *reinterpret_cast<f32x4*>(op + 8 * g4) = a;
+            *reinterpret_cast<f32x4*>(op + 32 + 8 * g4) = c;
+        }
+    }
+}
+
+int attention_f32(const float* qkv, float* out, int B, int T, int heads, int mode,
+                  const uint8_t* key_mask, hipStream_t s) {
+    TSTAR_REQUIRE(B > 0 && T > 0 && heads > 0, "attention_f32: empty problem");
+    TSTAR_REQUIRE(mode == 0 || (mode == 1 && key_mask != nullptr), "attention_f32: mode 1 needs key_mask");
+    const int qtiles = cdiv(T, 128);
+    const int grid = B * heads * qtiles;
+    if (mode == 0)
+        hipLaunchKernelGGL(attention_f32_kernel<0>, dim3(grid), dim3(256), 0, s, qkv, out, T, heads, qtiles, key_mask);
+    else
+        hipLaunchKernelGGL(attention_f32_kernel<1>, dim3(grid), dim3(256), 0, s, qkv, out, T, heads, qtiles, key_mask);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
+}  // namespace tstar

@@ -1,0 +1,370 @@
+// C ABI of libtstar_hip.so (include/tstar_hip.h): handle management and the
+// OWL-ViT-B/32 forward orchestration over the hand-written gfx950 kernels.
+#include "../../include/tstar_hip.h"
+#include "common.h"
+#include "heads.h"
+#include "kernels.h"
+#include "owl_weights.h"
+#include <math.h>
+#include <map>
+#include <string.h>
+#include <vector>
+
+namespace tstar {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// ---------------------------------------------------------------- small text-tower kernels
+// x[q*T + t, :] = tok_emb[ids[q,t], :] + pos_emb[t, :]   (OwlViTTextEmbeddings, modeling_owlvit.py:356-372)
+__global__ void embed_tokens_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
+                                    const float* __restrict__ pos, float* __restrict__ x, int T, int D) {
+    const int r = blockIdx.x;
+    const size_t id = (size_t)ids[r];
+    const int t = r % T;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) x[(size_t)r * D + d] = tok[id * D + d] + pos[(size_t)t * D + d];
+}
+// y[q, :] = x[q*T + eos[q], :]  (EOS pooling, modeling_owlvit.py:651-658)
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ eos, float* __restrict__ y,
+                                   int T, int D) {
+    const int q = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) y[(size_t)q * D + d] = x[((size_t)q * T + eos[q]) * D + d];
+}
+// out[q,:] = in[q,:] / (||in[q,:]|| + eps); one wave per row, D = 512
+__global__ void l2norm_rows_kernel(const float* __restrict__ in, float* __restrict__ out, float eps) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    float v[8], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = in[(size_t)q * 512 + i * 64 + lane]; s += v[i] * v[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float den = sqrtf(s) + eps;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[(size_t)q * 512 + i * 64 + lane] = v[i] / den;
+}
+}  // namespace tstar
+
+using namespace tstar;
+
+struct tstar_owl {
+    float* d_vision = nullptr;
+    float* d_text = nullptr;
+    VisionW vw{};
+    TextW tw{};
+    bool has_text = false;
+    float* d_lut = nullptr;
+    int max_batch = 0;
+    size_t mpad = 0;
+    // activation workspace (per chunk of max_batch images)
+    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    uint8_t* tmp_u8 = nullptr; size_t tmp_u8_bytes = 0;
+    // queries
+    int Q = 0;
+    float *q_raw = nullptr, *qn = nullptr, *qweight = nullptr;
+    uint8_t* qmask = nullptr;
+    int *d_ids = nullptr, *d_eos = nullptr;
+    uint8_t* d_kmask = nullptr;
+    std::map<int, ResampleTable> tabs;   // in_size -> table to 768
+};
+
+static size_t padded(size_t n) { return (n + 63) / 64 * 64; }
+
+template <class MapFn>
+static int upload_blob(const float* h_blob, size_t n_expected_check, float** d_out, MapFn&& mapfn) {
+    // pass 1: sizes
+    size_t packed = 0, pad_total = 0;
+    std::vector<std::pair<size_t, size_t>> ents;   // (packed offset, n)
+    auto count = [&](size_t n) -> const float* { ents.push_back({packed, n}); packed += n; pad_total += padded(n); return nullptr; };
+    mapfn(count);
+    if (packed != n_expected_check) {
+        set_error("weight blob has " + std::to_string(n_expected_check) + " floats, layout wants " + std::to_string(packed));
+        return TSTAR_ERR_ARG;
+    }
+    float* d = nullptr;
+    TSTAR_HIP_CHECK(hipMalloc(&d, pad_total * sizeof(float)));
+    TSTAR_HIP_CHECK(hipMemset(d, 0, pad_total * sizeof(float)));
+    size_t off = 0, i = 0;
+    int rc = TSTAR_OK;
+    auto place = [&](size_t n) -> const float* {
+        const float* p = d + off;
+        if (hipMemcpy(d + off, h_blob + ents[i].first, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = TSTAR_ERR_HIP;
+        off += padded(n); ++i;
+        return p;
+    };
+    mapfn(place);
+    if (rc) { set_error("hipMemcpy of weights failed"); (void)hipFree(d); return rc; }
+    *d_out = d;
+    return TSTAR_OK;
+}
+
+static size_t vision_floats() {
+    size_t n = 0; VisionW w; map_vision(w, [&](size_t k) -> const float* { n += k; return nullptr; }); return n;
+}
+static size_t text_floats() {
+    size_t n = 0; TextW w; map_text(w, [&](size_t k) -> const float* { n += k; return nullptr; }); return n;
+}
+
+static int get_table(tstar_owl* h, int in_size, ResampleTable** out, hipStream_t s) {
+    auto it = h->tabs.find(in_size);
+    if (it == h->tabs.end()) {
+        ResampleTable t;
+        int rc = build_bicubic_table(&t, in_size, 768, s);
+        if (rc) return rc;
+        it = h->tabs.emplace(in_size, t).first;
+    }
+    *out = &it->second;
+    return TSTAR_OK;
+}
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+static GemmArgs mk_gemm(const float* A, const float* W, float* C, const float* bias, const float* res, int M, int N,
+                        int K, int lda, int ldc, int act) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0;
+    return g;
+}
+
+// CLIP pre-LN encoder stack shared by both towers; x [M,D] updated in place
+static int run_encoder(tstar_owl* h, const LayerW* layers, int nlayers, int B, int T, int D, int FF, int heads,
+                       int mode, const uint8_t* key_mask, hipStream_t s) {
+    const int M = B * T;
+    for (int l = 0; l < nlayers; ++l) {
+        const LayerW& w = layers[l];
+        RC(layernorm_f32(h->x, h->xn, w.ln1_w, w.ln1_b, M, D, s));
+        RC(gemm_f32(mk_gemm(h->xn, w.qkv_w, h->qkv, w.qkv_b, nullptr, M, 3 * D, D, D, 3 * D, ACT_NONE), s));
+        RC(attention_f32(h->qkv, h->att, B, T, heads, mode, key_mask, s));
+        RC(gemm_f32(mk_gemm(h->att, w.out_w, h->x, w.out_b, h->x, M, D, D, D, D, ACT_NONE), s));
+        RC(layernorm_f32(h->x, h->xn, w.ln2_w, w.ln2_b, M, D, s));
+        RC(gemm_f32(mk_gemm(h->xn, w.fc1_w, h->hid, w.fc1_b, nullptr, M, FF, D, D, FF, ACT_QGELU), s));
+        RC(gemm_f32(mk_gemm(h->hid, w.fc2_w, h->x, w.fc2_b, h->x, M, D, FF, FF, D, ACT_NONE), s));
+    }
+    return TSTAR_OK;
+}
+
+static int preprocess_chunk(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, uint8_t* out_u8,
+                            float* out_patches, hipStream_t s) {
+    ResampleTable *th, *tv;
+    RC(get_table(h, W, &th, s));
+    RC(get_table(h, H, &tv, s));
+    const size_t need = (size_t)B * H * 768 * 3;
+    if (need > h->tmp_u8_bytes) {
+        TSTAR_HIP_CHECK(hipStreamSynchronize(s));
+        if (h->tmp_u8) TSTAR_HIP_CHECK(hipFree(h->tmp_u8));
+        h->tmp_u8 = nullptr; h->tmp_u8_bytes = 0;
+        TSTAR_HIP_CHECK(hipMalloc(&h->tmp_u8, need));
+        h->tmp_u8_bytes = need;
+    }
+    RC(resample_h_u8(d_images, h->tmp_u8, B, H, W, *th, s));
+    RC(resample_v_normalize_patchify(h->tmp_u8, out_patches, out_u8, B, H, *tv, h->d_lut, s));
+    return TSTAR_OK;
+}
+
+extern "C" {
+
+const char* tstar_last_error(void) { return g_err.c_str(); }
+int tstar_abi_version(void) { return 1; }
+size_t tstar_owl_vision_blob_floats(void) { return vision_floats(); }
+size_t tstar_owl_text_blob_floats(void) { return text_floats(); }
+
+int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision, const float* h_text_blob,
+                     size_t n_text, const float* h_norm_lut, int max_batch) {
+    TSTAR_REQUIRE(out && h_vision_blob && h_norm_lut, "tstar_owl_create: null argument");
+    TSTAR_REQUIRE(max_batch >= 1 && max_batch <= 1024, "tstar_owl_create: max_batch must be in 1..1024");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("tstar_owl_create: no HIP device visible (this library has no CPU path)");
+        return TSTAR_ERR_HIP;
+    }
+    tstar_owl* h = new tstar_owl();
+    int rc = upload_blob(h_vision_blob, n_vision, &h->d_vision,
+                         [&](auto&& take) { map_vision(h->vw, take); });
+    if (rc) { delete h; return rc; }
+    if (h_text_blob) {
+        rc = upload_blob(h_text_blob, n_text, &h->d_text, [&](auto&& take) { map_text(h->tw, take); });
+        if (rc) { tstar_owl_destroy(h); return rc; }
+        h->has_text = true;
+    }
+    h->max_batch = max_batch;
+    h->mpad = round_up((size_t)max_batch * V_NTOK, 128);
+    const size_t mp = h->mpad;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](float** p, size_t n) { if (e == hipSuccess) { e = hipMalloc(p, n * sizeof(float)); if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(float)); } };
+    alloc(&h->x, mp * V_D); alloc(&h->xn, mp * V_D); alloc(&h->qkv, mp * 3 * V_D); alloc(&h->att, mp * V_D);
+    alloc(&h->hid, mp * V_FF);
+    alloc(&h->d_lut, 768);
+    alloc(&h->q_raw, TSTAR_OWL_MAX_QUERIES * PROJ); alloc(&h->qn, TSTAR_OWL_MAX_QUERIES * PROJ);
+    alloc(&h->qweight, TSTAR_OWL_MAX_QUERIES);
+    if (e == hipSuccess) e = hipMalloc(&h->qmask, TSTAR_OWL_MAX_QUERIES);
+    if (e == hipSuccess) e = hipMalloc(&h->d_ids, TSTAR_OWL_MAX_QUERIES * T_LEN * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->d_eos, TSTAR_OWL_MAX_QUERIES * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->d_kmask, TSTAR_OWL_MAX_QUERIES * T_LEN);
+    if (e == hipSuccess) e = hipMemcpy(h->d_lut, h_norm_lut, 768 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error(std::string("tstar_owl_create: workspace allocation failed: ") + hipGetErrorString(e));
+        tstar_owl_destroy(h);
+        return TSTAR_ERR_HIP;
+    }
+    *out = h;
+    return TSTAR_OK;
+}
+
+int tstar_owl_destroy(tstar_owl* h) {
+    if (!h) return TSTAR_OK;
+    void* ptrs[] = {h->d_vision, h->d_text, h->d_lut, h->x, h->xn, h->qkv, h->att, h->hid, h->tmp_u8, h->q_raw,
+                    h->qn, h->qweight, h->qmask, h->d_ids, h->d_eos, h->d_kmask};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& kv : h->tabs) free_table(&kv.second);
+    delete h;
+    return TSTAR_OK;
+}
+
+static int finish_queries(tstar_owl* h, const uint8_t* h_mask, const float* h_w, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->q_raw, h->qn, 1e-6f);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qmask, h_mask, Q, hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight, h_w, Q * sizeof(float), hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(s));
+    h->Q = Q;
+    return TSTAR_OK;
+}
+
+int tstar_owl_set_queries(tstar_owl* h, const int32_t* h_ids, const int32_t* h_am, const float* h_w, int Q,
+                          void* stream) {
+    TSTAR_REQUIRE(h && h_ids && h_am && h_w, "tstar_owl_set_queries: null argument");
+    TSTAR_REQUIRE(Q >= 1 && Q <= TSTAR_OWL_MAX_QUERIES, "tstar_owl_set_queries: Q must be in 1..32");
+    if (!h->has_text) { set_error("tstar_owl_set_queries: handle was created without text weights"); return TSTAR_ERR_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> eos(Q);
+    std::vector<uint8_t> km(Q * T_LEN), qm(Q);
+    for (int q = 0; q < Q; ++q) {
+        int best = 0;
+        for (int t = 0; t < T_LEN; ++t) {
+            const int id = h_ids[q * T_LEN + t];
+            TSTAR_REQUIRE(id >= 0 && id < T_VOCAB, "tstar_owl_set_queries: token id out of range");
+            if (id > h_ids[q * T_LEN + best]) best = t;        // argmax, first occurrence
+            km[q * T_LEN + t] = h_am[q * T_LEN + t] != 0;
+        }
+        eos[q] = best;
+        qm[q] = h_ids[q * T_LEN] > 0;                          // modeling_owlvit.py:1447
+    }
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_ids, h_ids, Q * T_LEN * sizeof(int), hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_eos, eos.data(), Q * sizeof(int), hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_kmask, km.data(), Q * T_LEN, hipMemcpyHostToDevice, s));
+    const int M = Q * T_LEN;
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(128), 0, s, h->d_ids, h->tw.tok_emb, h->tw.tpos_emb, h->x,
+                       T_LEN, T_D);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    RC(run_encoder(h, h->tw.layers, T_LAYERS, Q, T_LEN, T_D, T_FF, T_HEADS, 1, h->d_kmask, s));
+    RC(layernorm_f32(h->x, h->xn, h->tw.final_ln_w, h->tw.final_ln_b, M, T_D, s));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(Q), dim3(128), 0, s, h->xn, h->d_eos, h->att, T_LEN, T_D);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    RC(gemm_f32(mk_gemm(h->att, h->tw.text_proj, h->hid, nullptr, nullptr, Q, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->hid, h->q_raw, 0.0f);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return finish_queries(h, qm.data(), h_w, Q, s);
+}
+
+int tstar_owl_set_query_embeds(tstar_owl* h, const float* h_qe, const uint8_t* h_mask, const float* h_w, int Q,
+                               void* stream) {
+    TSTAR_REQUIRE(h && h_qe && h_mask && h_w, "tstar_owl_set_query_embeds: null argument");
+    TSTAR_REQUIRE(Q >= 1 && Q <= TSTAR_OWL_MAX_QUERIES, "tstar_owl_set_query_embeds: Q must be in 1..32");
+    hipStream_t s = (hipStream_t)stream;
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->q_raw, h_qe, (size_t)Q * PROJ * sizeof(float), hipMemcpyHostToDevice, s));
+    return finish_queries(h, h_mask, h_w, Q, s);
+}
+
+int tstar_owl_get_query_embeds(tstar_owl* h, float* h_out, int Q, void* stream) {
+    TSTAR_REQUIRE(h && h_out, "tstar_owl_get_query_embeds: null argument");
+    TSTAR_REQUIRE(Q == h->Q, "tstar_owl_get_query_embeds: Q does not match the installed queries");
+    hipStream_t s = (hipStream_t)stream;
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h_out, h->q_raw, (size_t)Q * PROJ * sizeof(float), hipMemcpyDeviceToHost, s));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(s));
+    return TSTAR_OK;
+}
+
+int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
+                    float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
+                    uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits, float* d_boxes_cxcywh, void* stream) {
+    TSTAR_REQUIRE(h && d_images && d_scores && d_labels && d_boxes_xyxy && d_cell_conf && d_cell_mask,
+                  "tstar_owl_score: null argument");
+    TSTAR_REQUIRE(B >= 1 && H >= 1 && W >= 1, "tstar_owl_score: empty batch or image");
+    TSTAR_REQUIRE(grid_rows >= 1 && grid_cols >= 1, "tstar_owl_score: grid must be at least 1x1");
+    if (h->Q == 0) { set_error("tstar_owl_score: no queries installed (call tstar_owl_set_queries first)"); return TSTAR_ERR_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int ncell = grid_rows * grid_cols;
+    for (int b0 = 0; b0 < B; b0 += h->max_batch) {
+        const int Bc = (B - b0) < h->max_batch ? (B - b0) : h->max_batch;
+        const int M = Bc * V_NTOK, MP = Bc * V_NP;
+        RC(preprocess_chunk(h, d_images + (size_t)b0 * H * W * 3, Bc, H, W, nullptr, h->hid, s));
+        GemmArgs pg = mk_gemm(h->hid, h->vw.patch_w, h->x, nullptr, nullptr, MP, V_D, V_PATCH_K, V_PATCH_K, V_D, ACT_NONE);
+        pg.pos = h->vw.pos_emb; pg.patch_np = V_NP;
+        RC(gemm_f32(pg, s));
+        RC(write_cls_rows(h->x, h->vw.class_emb, h->vw.pos_emb, Bc, V_NTOK, V_D, s));
+        RC(layernorm_f32(h->x, h->x, h->vw.pre_ln_w, h->vw.pre_ln_b, M, V_D, s));
+        RC(run_encoder(h, h->vw.layers, V_LAYERS, Bc, V_NTOK, V_D, V_FF, V_HEADS, 0, nullptr, s));
+        float* feats = h->xn;
+        RC(merge_cls_ln(h->x, feats, h->vw.post_ln_w, h->vw.post_ln_b, h->vw.det_ln_w, h->vw.det_ln_b, Bc, V_NTOK, V_D, s));
+        float* cls = h->att;      // [MP, 512]
+        float* bh1 = h->qkv;      // [MP, 768]
+        float* bh2 = h->hid;      // [MP, 768]
+        RC(gemm_f32(mk_gemm(feats, h->vw.cls_w, cls, h->vw.cls_b, nullptr, MP, PROJ, V_D, V_D, PROJ, ACT_NONE), s));
+        RC(gemm_f32(mk_gemm(feats, h->vw.box0_w, bh1, h->vw.box0_b, nullptr, MP, V_D, V_D, V_D, V_D, ACT_GELU), s));
+        RC(gemm_f32(mk_gemm(bh1, h->vw.box1_w, bh2, h->vw.box1_b, nullptr, MP, V_D, V_D, V_D, V_D, ACT_GELU), s));
+        DetectRowsArgs a{};
+        a.feats = feats; a.cls = cls; a.boxh = bh2; a.qn = h->qn; a.qmask = h->qmask;
+        a.shift_w = h->vw.shift_w; a.shift_b = h->vw.shift_b; a.scale_w = h->vw.scale_w; a.scale_b = h->vw.scale_b;
+        a.box2_w = h->vw.box2_w; a.box2_b = h->vw.box2_b; a.box_bias = h->vw.box_bias;
+        a.scores = d_scores + (size_t)b0 * V_NP;
+        a.labels = d_labels + (size_t)b0 * V_NP;
+        a.xyxy = d_boxes_xyxy + (size_t)b0 * V_NP * 4;
+        a.logits = d_logits ? d_logits + (size_t)b0 * V_NP * h->Q : nullptr;
+        a.cxcywh = d_boxes_cxcywh ? d_boxes_cxcywh + (size_t)b0 * V_NP * 4 : nullptr;
+        a.rows = MP; a.np = V_NP; a.Q = h->Q; a.img_w = W; a.img_h = H;
+        RC(detect_rows(a, s));
+        RC(cell_reduce(a.scores, a.labels, a.xyxy, h->qweight, Bc, V_NP, W, H, grid_rows, grid_cols, 0.005f,
+                       d_cell_conf + (size_t)b0 * ncell, d_cell_mask + (size_t)b0 * ncell,
+                       d_n_kept ? d_n_kept + b0 : nullptr, s));
+    }
+    return TSTAR_OK;
+}
+
+int tstar_owl_debug_preprocess(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, uint8_t* d_out_u8,
+                               float* d_out_patches, void* stream) {
+    TSTAR_REQUIRE(h && d_images && d_out_patches, "tstar_owl_debug_preprocess: null argument");
+    TSTAR_REQUIRE(B >= 1 && B <= h->max_batch, "tstar_owl_debug_preprocess: B must be in 1..max_batch");
+    return preprocess_chunk(h, d_images, B, H, W, d_out_u8, d_out_patches, (hipStream_t)stream);
+}
+
+int tstar_frames_to_grid(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int grid_rows,
+                         int grid_cols, uint8_t* d_grid, void* stream) {
+    TSTAR_REQUIRE(d_video && d_frame_idx && d_grid, "tstar_frames_to_grid: null argument");
+    TSTAR_REQUIRE(N >= 1 && H >= 2 && W >= 2, "tstar_frames_to_grid: bad video shape");
+    return frames_to_grid_u8(d_video, H, W, d_frame_idx, grid_rows, grid_cols, 200, 95, d_grid, (hipStream_t)stream);
+}
+
+int tstar_frames_resize(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n, int out_w,
+                        int out_h, uint8_t* d_out, void* stream) {
+    TSTAR_REQUIRE(d_video && d_frame_idx && d_out, "tstar_frames_resize: null argument");
+    TSTAR_REQUIRE(N >= 1 && H >= 2 && W >= 2, "tstar_frames_resize: bad video shape");
+    return bilinear_gather_u8(d_video, H, W, d_frame_idx, n, out_w, out_h, d_out, (hipStream_t)stream);
+}
+
+int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
+                   int N, int K, int act, void* stream) {
+    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32: null argument");
+    return gemm_f32(mk_gemm(d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act), (hipStream_t)stream);
+}
+
+int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream) {
+    TSTAR_REQUIRE(d_x && d_y && d_w && d_b, "tstar_layernorm_f32: null argument");
+    return layernorm_f32(d_x, d_y, d_w, d_b, rows, D, (hipStream_t)stream);
+}
+
+int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode, const uint8_t* d_key_mask,
+                        void* stream) {
+    TSTAR_REQUIRE(d_qkv && d_out, "tstar_attention_f32: null argument");
+    return attention_f32(d_qkv, d_out, B, T, heads, mode, d_key_mask, (hipStream_t)stream);
+}
+
+}  // extern "C"

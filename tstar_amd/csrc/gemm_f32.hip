@@ -1,0 +1,196 @@
+// fp32 GEMM on the CDNA4 matrix cores: C[M,N] = A[M,K] * W[N,K]^T (+ fused epilogue).
+//
+// This is the dominant kernel of the OWL-ViT scorer (patch-embed, QKV, out-proj,
+// fc1, fc2, head projections: 112.8 of the 114.8 GFLOP per detector image,
+// SURVEY.md 8d).  It replaces the torch.nn.Linear / Conv2d calls HF makes in
+// modeling_owlvit.py:336-337, 428-459, 471-475, 993-999, 1020 on behalf of
+// /root/reference/TStar/interface_heuristic.py:237-239.
+//
+// Design (gfx950):
+//  * v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain), 64 cycles per
+//    SIMD per issue, 157.3 TFLOP/s chip peak.  There is no TF32 on CDNA4.
+//  * 128x128x32 block tile, 256 threads = 4 waves (2x2), each wave 64x64 =
+//    2x2 MFMA tiles (64 accumulator VGPRs).  2 blocks per CU so one block's
+//    MFMA stream covers the other's barrier / LDS-write bubbles.
+//  * both operands are K-contiguous (activations row-major, nn.Linear weight
+//    [out,in]) -> identical staging for A and W: global_load_dwordx4 ->
+//    ds_write_b128 into a [128][32+4] padded tile (row stride 144 B makes the
+//    ds_read_b128 fragment reads conflict-free: 36*r mod 64 hits 16 distinct
+//    4-bank slots for r = 0..15), double-buffered, ONE barrier per K tile.
+//  * a lane's b128 read delivers 4 consecutive k values; lanes 0-31 take
+//    k = 8q..8q+3, lanes 32-63 k = 8q+4..8q+7, so four MFMAs consume one read
+//    (the k-slot <-> k-index assignment of an MFMA is free as long as A and B
+//    agree).
+//  * 1-D grid with an XCD-aware bijective remap: consecutive tiles (same A row
+//    panel) land on the same XCD's L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace tstar {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
+constexpr int GEMM_LDS_BYTES = 2 /*buf*/ * 2 /*A,B*/ * BM * LDS_LD * 4;
+
+__device__ __forceinline__ float epi_act(float v, int act) {
+    if (act == ACT_QGELU) return v / (1.0f + expf(-1.702f * v));
+    if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
+
+    const int nt = g.N / BN;
+    const int mt = (g.M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // staging assignment: thread -> (row r0 + 32 i, float4 column c4)
+    const int c4 = t & 7, r0 = t >> 3;
+    const float* ap[4];
+    const float* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ar = m0 + r0 + 32 * i;
+        ar = ar < g.M ? ar : g.M - 1;           // clamp: never read past the last row
+        ap[i] = g.A + (size_t)ar * g.lda + c4 * 4;
+        bp[i] = g.W + (size_t)(n0 + r0 + 32 * i) * g.K + c4 * 4;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const f32x4*>(ap[i]);
+        rb[i] = *reinterpret_cast<const f32x4*>(bp[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+        *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
+    }
+    __syncthreads();
+
+    const int nk = g.K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * BK);
+                rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + (kt + 1) * BK);
+            }
+        }
+        const float* Ac = As + cur * BM * LDS_LD + (wm * 64 + l31) * LDS_LD + h * 4;
+        const float* Bc = Bs + cur * BN * LDS_LD + (wn * 64 + l31) * LDS_LD + h * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(Ac + kk * 8);
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(Ac + 32 * LDS_LD + kk * 8);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(Bc + kk * 8);
+            f32x4 b1 = *reinterpret_cast<const f32x4*>(Bc + 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            float* Aw = As + (cur ^ 1) * BM * LDS_LD;
+            float* Bw = Bs + (cur ^ 1) * BN * LDS_LD;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(&Aw[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+                *reinterpret_cast<f32x4*>(&Bw[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const float bv = HAS_BIAS ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    v = epi_act(v, ACT);
+                    size_t orow = row;
+                    if (PATCH) {
+                        // patch-embed rows (b, p) -> token rows (b, 1 + p), + position embedding
+                        const int b = row / g.patch_np, p = row - b * g.patch_np;
+                        orow = (size_t)b * (g.patch_np + 1) + 1 + p;
+                        v += g.pos[(size_t)(1 + p) * g.N + col];
+                    }
+                    if (HAS_RES) v += g.res[orow * g.ldc + col];
+                    g.C[orow * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+static int launch_one(const GemmArgs& g, hipStream_t stream) {
+    auto kern = gemm_f32_kernel<ACT, HAS_BIAS, HAS_RES, PATCH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        attr_set = true;
+    }
+    const int nwg = cdiv(g.M, BM) * (g.N / BN);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), GEMM_LDS_BYTES, stream, g);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
+int gemm_f32(const GemmArgs& g, hipStream_t stream) {
+    TSTAR_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_f32: empty problem");
+    TSTAR_REQUIRE(g.N % BN == 0, "gemm_f32: N must be a multiple of 128");
+    TSTAR_REQUIRE(g.K % BK == 0, "gemm_f32: K must be a multiple of 32");
+    TSTAR_REQUIRE(g.lda % 4 == 0 && g.K % 4 == 0, "gemm_f32: rows must be 16-byte aligned");
+    const bool bias = g.bias != nullptr, res = g.res != nullptr, patch = g.pos != nullptr;
+    if (patch) {
+        TSTAR_REQUIRE(!bias && !res && g.act == ACT_NONE && g.patch_np > 0, "gemm_f32: patch epilogue takes no bias/res/act");
+        return launch_one<ACT_NONE, false, false, true>(g, stream);
+    }
+    if (g.act == ACT_QGELU) {
+        TSTAR_REQUIRE(bias && !res, "gemm_f32: quick-gelu epilogue needs bias, no residual");
+        return launch_one<ACT_QGELU, true, false, false>(g, stream);
+    }
+    if (g.act == ACT_GELU) {
+        TSTAR_REQUIRE(bias && !res, "gemm_f32: gelu epilogue needs bias, no residual");
+        return launch_one<ACT_GELU, true, false, false>(g, stream);
+    }
+    if (bias && res) return launch_one<ACT_NONE, true, true, false>(g, stream);
+    if (bias) return launch_one<ACT_NONE, true, false, false>(g, stream);
+    TSTAR_REQUIRE(!res, "gemm_f32: residual without bias is not instantiated");
+    return launch_one<ACT_NONE, false, false, false>(g, stream);
+}
+
+}  // namespace tstar

@@ -1,0 +1,37 @@
+// Internal launcher declarations (not part of the C ABI; see include/tstar_hip.h).
+#pragma once
+#include "common.h"
+
+namespace tstar {
+
+enum { ACT_NONE = 0, ACT_QGELU = 1, ACT_GELU = 2 };
+
+struct GemmArgs {
+    const float* A;      // [M, lda] row-major, K contiguous
+    const float* W;      // [N, K] row-major (nn.Linear layout)
+    float* C;            // [*, ldc]
+    const float* bias;   // [N] or null
+    const float* res;    // residual, same layout as C, or null (may alias C)
+    const float* pos;    // patch-embed epilogue: position embedding [np+1, N], or null
+    int M, N, K, lda, ldc;
+    int act;             // ACT_*
+    int patch_np;        // patches per image (576) for the patch-embed epilogue
+};
+int gemm_f32(const GemmArgs& g, hipStream_t stream);
+
+// y[r,:] = LayerNorm(x[r,:]) * w + b over D (eps 1e-5, biased variance); D % 256 == 0, D <= 1024
+int layernorm_f32(const float* x, float* y, const float* w, const float* b, int rows, int D, hipStream_t s);
+
+// x[b,0,:] = cls + pos[0] (token row 0 of every image); x is [B*ntok, D]
+int write_cls_rows(float* x, const float* cls, const float* pos, int B, int ntok, int D, hipStream_t s);
+
+// feats[b,p,:] = LN_det( LN_post(x[b,1+p,:]) * LN_post(x[b,0,:]) )
+int merge_cls_ln(const float* x, float* feats, const float* post_w, const float* post_b,
+                 const float* det_w, const float* det_b, int B, int ntok, int D, hipStream_t s);
+
+// multi-head self-attention over packed qkv [B*T, 3*D] (q | k | v, heads of 64) -> out [B*T, D]
+// mode 0: full attention; mode 1: causal + key padding mask (key_mask [B,T] u8, 0 = masked)
+int attention_f32(const float* qkv, float* out, int B, int T, int heads, int mode,
+                  const uint8_t* key_mask, hipStream_t s);
+
+}  // namespace tstar

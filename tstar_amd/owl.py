@@ -1,0 +1,163 @@
+"""Host wrapper of the HIP OWL-ViT-B/32 scorer (tstar_owl_* in include/tstar_hip.h).
+
+PyTorch is used for device memory and streams only; every computation is a
+hand-written gfx950 kernel behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from . import weights as W
+
+# CLIP normalisation constants (transformers/utils/constants.py:5-6)
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def normalize_lut() -> np.ndarray:
+    """f32 [3,256]: value of (channel, u8) after HF rescale + normalize.
+
+    Restates transformers image_transforms.py rescale (:118-122: f64(u8) * (1/255)
+    -> f32) and normalize (:419-437: (x - f32(mean)) / f32(std) in f32), the
+    arithmetic OWLInterface.inference_detector reaches through
+    ``self.processor(...)`` (/root/reference/TStar/interface_heuristic.py:234).
+    """
+    u = np.arange(256, dtype=np.uint8)
+    x = (u.astype(np.float64) * (1 / 255)).astype(np.float32)
+    mean = np.array(OPENAI_CLIP_MEAN, dtype=np.float32)
+    std = np.array(OPENAI_CLIP_STD, dtype=np.float32)
+    lut = (x[None, :] - mean[:, None]) / std[:, None]
+    return np.ascontiguousarray(lut.astype(np.float32))
+
+
+@dataclass
+class ScoreResult:
+    """Device tensors produced by one tstar_owl_score call."""
+    scores: "object"       # f32 [B,576]
+    labels: "object"       # i32 [B,576]
+    boxes: "object"        # f32 [B,576,4] xyxy pixels
+    cell_conf: "object"    # f64 [B,rows*cols]
+    cell_mask: "object"    # i32 view of u32 [B,rows*cols]
+    n_kept: "object"       # i32 [B]
+    logits: "object" = None
+    boxes_cxcywh: "object" = None
+
+
+class OwlScorer:
+    """One OWL-ViT-B/32 scorer resident on the current HIP device."""
+
+    def __init__(self, vision_blob: np.ndarray, text_blob: Optional[np.ndarray] = None, max_batch: int = 32):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.TStarHipError("OwlScorer needs a HIP device (torch.cuda.is_available() is False); "
+                                     "tstar_amd has no CPU path")
+        self._torch = torch
+        self._lib = _lib.load()
+        vision_blob = np.ascontiguousarray(vision_blob, dtype=np.float32)
+        if text_blob is not None:
+            text_blob = np.ascontiguousarray(text_blob, dtype=np.float32)
+        lut = normalize_lut()
+        h = C.c_void_p()
+        rc = self._lib.tstar_owl_create(
+            C.byref(h), vision_blob.ctypes.data, vision_blob.size,
+            None if text_blob is None else text_blob.ctypes.data, 0 if text_blob is None else text_blob.size,
+            lut.ctypes.data, int(max_batch))
+        _lib.check(rc, "tstar_owl_create")
+        self._h = h
+        self.max_batch = int(max_batch)
+        self.Q = 0
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    @classmethod
+    def synthetic(cls, seed: int = 0, max_batch: int = 32, with_text: bool = True):
+        sd = W.synthetic_state_dict(seed, "both" if with_text else "vision")
+        vb = W.pack_blob(sd, W.vision_spec())
+        tb = W.pack_blob(sd, W.text_spec()) if with_text else None
+        return cls(vb, tb, max_batch)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tstar_owl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- queries
+    def set_queries(self, input_ids: np.ndarray, attention_mask: np.ndarray, class_weight: Sequence[float]):
+        ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+        am = np.ascontiguousarray(attention_mask, dtype=np.int32)
+        w = np.ascontiguousarray(class_weight, dtype=np.float32)
+        Q = ids.shape[0]
+        if ids.shape != (Q, W.T_LEN) or am.shape != ids.shape or w.shape != (Q,):
+            raise ValueError("set_queries: ids/mask must be [Q,16] and class_weight [Q]")
+        rc = self._lib.tstar_owl_set_queries(self._h, ids.ctypes.data, am.ctypes.data, w.ctypes.data, Q,
+                                             _lib.stream_ptr())
+        _lib.check(rc, "tstar_owl_set_queries")
+        self.Q = Q
+
+    def set_query_embeds(self, embeds: np.ndarray, query_mask: Sequence[int], class_weight: Sequence[float]):
+        e = np.ascontiguousarray(embeds, dtype=np.float32)
+        m = np.ascontiguousarray(query_mask, dtype=np.uint8)
+        w = np.ascontiguousarray(class_weight, dtype=np.float32)
+        Q = e.shape[0]
+        if e.shape != (Q, W.PROJ) or m.shape != (Q,) or w.shape != (Q,):
+            raise ValueError("set_query_embeds: embeds [Q,512], mask [Q], class_weight [Q]")
+        rc = self._lib.tstar_owl_set_query_embeds(self._h, e.ctypes.data, m.ctypes.data, w.ctypes.data, Q,
+                                                  _lib.stream_ptr())
+        _lib.check(rc, "tstar_owl_set_query_embeds")
+        self.Q = Q
+
+    def get_query_embeds(self) -> np.ndarray:
+        out = np.empty((self.Q, W.PROJ), dtype=np.float32)
+        rc = self._lib.tstar_owl_get_query_embeds(self._h, out.ctypes.data, self.Q, _lib.stream_ptr())
+        _lib.check(rc, "tstar_owl_get_query_embeds")
+        return out
+
+    # ---- scoring
+    def score(self, images, grid_rows: int, grid_cols: int, want_logits: bool = False) -> ScoreResult:
+        """images: torch u8 cuda tensor [B,H,W,3] (contiguous)."""
+        torch = self._torch
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3 or not images.is_cuda:
+            raise ValueError("score: images must be a cuda uint8 tensor [B,H,W,3]")
+        images = images.contiguous()
+        B, H, Wd, _ = images.shape
+        dev = images.device
+        ncell = grid_rows * grid_cols
+        r = ScoreResult(
+            scores=torch.empty((B, W.NPATCH), dtype=torch.float32, device=dev),
+            labels=torch.empty((B, W.NPATCH), dtype=torch.int32, device=dev),
+            boxes=torch.empty((B, W.NPATCH, 4), dtype=torch.float32, device=dev),
+            cell_conf=torch.empty((B, ncell), dtype=torch.float64, device=dev),
+            cell_mask=torch.empty((B, ncell), dtype=torch.int32, device=dev),
+            n_kept=torch.empty((B,), dtype=torch.int32, device=dev),
+        )
+        if want_logits:
+            r.logits = torch.empty((B, W.NPATCH, self.Q), dtype=torch.float32, device=dev)
+            r.boxes_cxcywh = torch.empty((B, W.NPATCH, 4), dtype=torch.float32, device=dev)
+        rc = self._lib.tstar_owl_score(
+            self._h, images.data_ptr(), B, H, Wd, grid_rows, grid_cols,
+            r.scores.data_ptr(), r.labels.data_ptr(), r.boxes.data_ptr(), r.cell_conf.data_ptr(),
+            r.cell_mask.data_ptr(), r.n_kept.data_ptr(),
+            _lib.ptr(r.logits), _lib.ptr(r.boxes_cxcywh), _lib.stream_ptr())
+        _lib.check(rc, "tstar_owl_score")
+        return r
+
+    def debug_preprocess(self, images):
+        torch = self._torch
+        images = images.contiguous()
+        B, H, Wd, _ = images.shape
+        u8 = torch.empty((B, 768, 768, 3), dtype=torch.uint8, device=images.device)
+        pat = torch.empty((B * W.NPATCH, 3 * W.PATCH * W.PATCH), dtype=torch.float32, device=images.device)
+        rc = self._lib.tstar_owl_debug_preprocess(self._h, images.data_ptr(), B, H, Wd, u8.data_ptr(),
+                                                  pat.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "tstar_owl_debug_preprocess")
+        return u8, pat
