@@ -47,7 +47,8 @@ def test_gemm_asymmetric_identity(lib):
     A = torch.eye(K)
     W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 1013) / 7.0
     dC = torch.empty((K, N), device="cuda")
-    _check(lib.tstar_gemm_f32(A.cuda().data_ptr(), W.cuda().data_ptr(), dC.data_ptr(), None, None, K, N, K, 0,
+    dA, dW = A.cuda(), W.cuda()          # keep the device tensors alive across the call
+    _check(lib.tstar_gemm_f32(dA.data_ptr(), dW.data_ptr(), dC.data_ptr(), None, None, K, N, K, 0,
                               torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert torch.equal(dC.cpu(), W.t().contiguous())
@@ -61,8 +62,8 @@ def test_gemm_residual_inplace(lib):
     b = torch.randn(N, generator=g)
     X = torch.randn(M, N, generator=g)
     ref = X + F.linear(A, W, b)
-    dX = X.cuda()
-    _check(lib.tstar_gemm_f32(A.cuda().data_ptr(), W.cuda().data_ptr(), dX.data_ptr(), b.cuda().data_ptr(),
+    dX, dA, dW, db = X.cuda(), A.cuda(), W.cuda(), b.cuda()
+    _check(lib.tstar_gemm_f32(dA.data_ptr(), dW.data_ptr(), dX.data_ptr(), db.data_ptr(),
                               dX.data_ptr(), M, N, K, 0, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert (dX.cpu() - ref).abs().max().item() < 5e-5
@@ -85,7 +86,8 @@ def test_layernorm(lib, rows, D):
     b = torch.randn(D, generator=g)
     ref = F.layer_norm(x, (D,), w, b, 1e-5)
     dy = torch.empty((rows, D), device="cuda")
-    _check(lib.tstar_layernorm_f32(x.cuda().data_ptr(), dy.data_ptr(), w.cuda().data_ptr(), b.cuda().data_ptr(),
+    dx, dw, db = x.cuda(), w.cuda(), b.cuda()
+    _check(lib.tstar_layernorm_f32(dx.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                    rows, D, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert (dy.cpu() - ref).abs().max().item() < 1e-5
@@ -111,7 +113,8 @@ def test_attention_full(lib, B, T, heads):
     qkv = torch.randn(B * T, 3 * D, generator=g)
     ref = _attn_ref(qkv, B, T, heads)
     out = torch.full((B * T, D), float("nan"), device="cuda")
-    _check(lib.tstar_attention_f32(qkv.cuda().data_ptr(), out.data_ptr(), B, T, heads, 0, None,
+    dqkv = qkv.cuda()
+    _check(lib.tstar_attention_f32(dqkv.data_ptr(), out.data_ptr(), B, T, heads, 0, None,
                                    torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max().item() < 2e-5
@@ -127,7 +130,8 @@ def test_attention_spiked_scores(lib):
     qkv[3, D:2 * D] *= 25.0          # and an early big one
     ref = _attn_ref(qkv, B, T, heads)
     out = torch.empty((B * T, D), device="cuda")
-    _check(lib.tstar_attention_f32(qkv.cuda().data_ptr(), out.data_ptr(), B, T, heads, 0, None,
+    dqkv = qkv.cuda()
+    _check(lib.tstar_attention_f32(dqkv.data_ptr(), out.data_ptr(), B, T, heads, 0, None,
                                    torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
@@ -149,7 +153,8 @@ def test_attention_causal_padded(lib):
     mask = (causal.view(1, 1, T, T) + pad).clamp_min(neg)
     ref = _attn_ref(qkv, B, T, heads, mask)
     out = torch.empty((B * T, D), device="cuda")
-    _check(lib.tstar_attention_f32(qkv.cuda().data_ptr(), out.data_ptr(), B, T, heads, 1, km.cuda().data_ptr(),
+    dqkv, dkm = qkv.cuda(), km.cuda()
+    _check(lib.tstar_attention_f32(dqkv.data_ptr(), out.data_ptr(), B, T, heads, 1, dkm.data_ptr(),
                                    torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     o = out.cpu().view(B, T, D)
