@@ -109,6 +109,39 @@ int tstar_frames_to_grid(const uint8_t* d_video, int N, int H, int W, const int3
 int tstar_frames_resize(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n,
                         int out_w, int out_h, uint8_t* d_out, void* stream);
 
+/* ------------------------------------------------------------------ searcher state (S-rows)
+ * Device-resident float64 state of one TStarSearcher (interface_searcher.py:73-75):
+ * score_distribution, non_visiting_frames, P, plus the sampler's working arrays.  All
+ * kernels are single-workgroup and reproduce numpy's operation order (pairwise sum,
+ * sequential cumsum, 'linear' percentile); see csrc/searcher.hip for the line map. */
+typedef struct tstar_searcher tstar_searcher;
+int tstar_searcher_create(tstar_searcher** out, int n_frames, double init_score, double init_p);
+int tstar_searcher_destroy(tstar_searcher* s);
+/* update_frame_distribution up to the spline fit (interface_searcher.py:302-313, 260-261):
+ * for the n sampled seconds (draw order) and their cell confidences d_conf f64 [n] (device,
+ * cell i <-> sample i): mark visited, write scores, top-25 % window spread; returns the
+ * visited frames (ascending) and their scores to the host for the FITPACK fit.  Synchronises. */
+int tstar_searcher_apply_grid(tstar_searcher* s, const int32_t* h_secs, const double* d_conf, int n,
+                              int* h_n_visited, int32_t* h_vis_x, double* h_vis_y, void* stream);
+/* spline_keyframe_distribution after the fit (interface_searcher.py:266-274): evaluates the
+ * B-spline (t, c, k) from scipy's UnivariateSpline at 0..N-1 (FITPACK splev, ext=0), clamps at
+ * 1/N, sigmoid, normalises -> P. */
+int tstar_searcher_set_spline(tstar_searcher* s, const double* h_t, const double* h_c, int n_knots, int k, void* stream);
+/* sample_frames' weights (interface_searcher.py:345-352) with add = num/N, and the cdf of
+ * np.random.choice; *h_fallback = 1 if the unvisited mask was dropped.  Synchronises. */
+int tstar_searcher_sampler_prep(tstar_searcher* s, int num, double add, int* h_fallback, void* stream);
+/* pop_frames' weights (interface_searcher.py:369) and their cdf. */
+int tstar_searcher_pop_prep(tstar_searcher* s, void* stream);
+/* cdf.searchsorted(x, 'right') for k host-drawn uniforms (the MT19937 stream stays on the host,
+ * numpy legacy RandomState.choice).  Synchronises. */
+int tstar_searcher_draw(tstar_searcher* s, const double* h_x, int k, int32_t* h_idx, void* stream);
+/* choice()'s retry step: p[found] = 0, cdf recomputed. */
+int tstar_searcher_exclude(tstar_searcher* s, const int32_t* h_found, int m, void* stream);
+/* verification overwrites (interface_searcher.py:407): score[secs[i]] = vals[i], in order. */
+int tstar_searcher_set_scores(tstar_searcher* s, const int32_t* h_secs, const double* h_vals, int m, void* stream);
+/* copy a state array to the host: 0 score, 1 non_visiting, 2 P, 3 sampler p, 4 cdf.  Synchronises. */
+int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* stream);
+
 /* ------------------------------------------------------------------ kernel-level diagnostics
  * (used by tests/ and bench.py to check and time individual kernels) */
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual); act: 0 none, 1 quick-gelu, 2 gelu(erf) */

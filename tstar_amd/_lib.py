@@ -34,6 +34,16 @@ SIGNATURES = {
     "tstar_owl_debug_preprocess": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tstar_frames_to_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "tstar_frames_resize": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "tstar_searcher_create": (_i, [C.POINTER(_vp), _i, C.c_double, C.c_double]),
+    "tstar_searcher_destroy": (_i, [_vp]),
+    "tstar_searcher_apply_grid": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "tstar_searcher_set_spline": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "tstar_searcher_sampler_prep": (_i, [_vp, _i, C.c_double, _vp, _vp]),
+    "tstar_searcher_pop_prep": (_i, [_vp, _vp]),
+    "tstar_searcher_draw": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "tstar_searcher_exclude": (_i, [_vp, _vp, _i, _vp]),
+    "tstar_searcher_set_scores": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "tstar_searcher_read": (_i, [_vp, _i, _vp, _vp]),
     "tstar_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tstar_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tstar_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

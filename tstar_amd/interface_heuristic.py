@@ -1,0 +1,159 @@
+"""Open-vocabulary detector plug-ins with the reference's duck-typed surface
+(/root/reference/TStar/interface_heuristic.py): ``HeuristicInterface`` (:28-37) and
+``OWLInterface`` (:200-280), backed by the HIP OWL-ViT-B/32 scorer instead of HF
+transformers + torch.
+
+Same names, argument meaning and behaviour as the reference where a caller can observe it:
+
+* ``reparameterize_object_list(target_objects, cue_objects)`` builds
+  ``texts = [[name.strip()], ..., [' ']]`` (:268-280, the trailing blank query included);
+* ``inference_detector(images, **kw)`` scores ONLY ``images[0]`` (:234), keeps detections with
+  score > 0.005 (:243) in patch order and returns ``[Detections]`` with ``.xyxy`` f32 [n,4]
+  (pixels of the passed image), ``.confidence`` f32 [n], ``.class_id`` int64 [n]; it also
+  refreshes ``self.detections_inbatch`` (:256);
+* ``bbox_visualization(images, detections_inbatch)`` draws on the arrays it is given (:259-267).
+
+Documented deviations: no ``./annotated_image.png`` is written per call (the reference's debug
+block, :248-255, costs ~50 ms per call); the text tower runs once per
+``reparameterize_object_list`` instead of once per detector call (it is constant per question);
+``YoloWorldInterface`` is not provided (its source is absent from the reference checkout --
+SURVEY.md 8c -- and it needs mmdet; requesting it raises NotImplementedError like an unknown
+heuristic type does in TStarFramework.initialize_heuristic, TStarFramework.py:187).
+
+Extensions used by tstar_amd.TStarSearcher's batched fast path (a foreign heuristic without them
+still works through ``inference_detector``): ``set_class_weights``, ``score_batch``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import weights as W
+from .tokenizer import encode_queries
+
+
+@dataclass
+class Detections:
+    """Minimal stand-in for ``supervision.Detections`` (the fields the searcher reads,
+    /root/reference/TStar/interface_searcher.py:134)."""
+    xyxy: np.ndarray
+    confidence: np.ndarray
+    class_id: np.ndarray
+
+    def __len__(self) -> int:
+        return int(self.xyxy.shape[0])
+
+
+class HeuristicInterface:
+    def __init__(self, heuristic_type: str = "owl-vit", **kwargs):
+        """Base of the detector plug-ins (empty in the reference too, interface_heuristic.py:28-37)."""
+
+
+class OWLInterface(HeuristicInterface):
+    def __init__(self, model_name_or_path: str = "google/owlvit-base-patch32", device: str = "cuda",
+                 max_batch: int = 32, synthetic_seed: Optional[int] = None, state_dict: Optional[Dict] = None):
+        """``device`` must be a HIP device (default "cuda" as in the reference, :201).
+
+        Weights: ``state_dict`` (HF names) if given; else a local safetensors checkpoint of
+        ``model_name_or_path`` if one exists on disk; else, only when ``synthetic_seed`` is not None,
+        seeded synthetic weights (no checkpoint can be downloaded: there is no network)."""
+        import torch
+        from .owl import OwlScorer
+        if not str(device).startswith("cuda"):
+            raise ValueError("tstar_amd.OWLInterface runs on the GPU only (device='cuda[:i]'); it has no CPU path")
+        dev = torch.device(device)
+        if dev.index is not None:
+            torch.cuda.set_device(dev.index)
+        if state_dict is None:
+            ckpt = W.find_pretrained(model_name_or_path)
+            if ckpt is not None:
+                state_dict = W.load_safetensors_state_dict(ckpt)
+                self.weights_source = ckpt
+            elif synthetic_seed is not None:
+                state_dict = W.synthetic_state_dict(int(synthetic_seed))
+                self.weights_source = f"synthetic(seed={int(synthetic_seed)})"
+            else:
+                raise FileNotFoundError(
+                    f"no local checkpoint for {model_name_or_path!r} (offline); pass synthetic_seed=<int> "
+                    "for seeded synthetic OWL-ViT-B/32 weights or state_dict=<HF state dict>")
+        else:
+            self.weights_source = "state_dict"
+        self.model_name_or_path = model_name_or_path
+        self.scorer = OwlScorer(W.pack_blob(state_dict, W.vision_spec()), W.pack_blob(state_dict, W.text_spec()),
+                                max_batch=max_batch)
+        self.device = device
+        self.texts = ["couch", "table", "woman"]      # as the reference leaves it before reparameterisation (:203)
+        self.detections_inbatch: List[Detections] = []
+        self._class_weight: Optional[np.ndarray] = None
+        self._ids = None
+
+    # ---- reference surface -------------------------------------------------------------
+    def reparameterize_object_list(self, target_objects: List[str], cue_objects: List[str]):
+        combined = list(target_objects) + list(cue_objects)
+        self.texts = [[obj.strip()] for obj in combined] + [[' ']]
+        ids, am = encode_queries(self.texts, self.model_name_or_path)
+        self._ids, self._am = ids, am
+        # default weights = the searcher's own defaults (target 1.0, cue 0.5, unknown 0.5;
+        # interface_searcher.py:88-91,136); a searcher overrides them via set_class_weights
+        w = [1.0] * len(target_objects) + [0.5] * len(cue_objects) + [0.5]
+        self.scorer.set_queries(ids, am, w)
+        self._class_weight = np.asarray(w, dtype=np.float32)
+
+    def inference_detector(self, images, **kwargs) -> List[Detections]:
+        import torch
+        img = np.ascontiguousarray(np.asarray(images[0], dtype=np.uint8))     # only image 0, as the reference
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("inference_detector expects HxWx3 uint8 RGB images")
+        d_img = torch.from_numpy(img).cuda().unsqueeze(0)
+        r = self.scorer.score(d_img, 1, 1)
+        dets = [self._detections_from(r, 0)]
+        self.detections_inbatch = dets
+        return dets
+
+    def bbox_visualization(self, images, detections_inbatch):
+        out = []
+        for image, det in zip(images, detections_inbatch):
+            out.append(draw_boxes(image, det))
+        return out
+
+    # ---- fast-path extensions ----------------------------------------------------------
+    def set_class_weights(self, object2weight: Dict[str, float]):
+        """Install ``object2weight.get(name, 0.5)`` per query (interface_searcher.py:136)."""
+        w = [float(object2weight.get(t[0], 0.5)) for t in self.texts]
+        self.scorer.set_queries(self._ids, self._am, w)
+        self._class_weight = np.asarray(w, dtype=np.float32)
+
+    def score_batch(self, d_images, grid_rows: int, grid_cols: int):
+        """Batched scoring of device images u8 [B,H,W,3] -> tstar_amd.owl.ScoreResult (device tensors)."""
+        return self.scorer.score(d_images, grid_rows, grid_cols)
+
+    def _detections_from(self, r, b: int) -> Detections:
+        s = r.scores[b].cpu().numpy()
+        keep = s > np.float32(0.005)
+        return Detections(xyxy=r.boxes[b].cpu().numpy()[keep], confidence=s[keep],
+                          class_id=r.labels[b].cpu().numpy()[keep].astype(np.int64))
+
+
+def draw_boxes(image: np.ndarray, det: Detections, color=(255, 64, 64)) -> np.ndarray:
+    """1-px rectangles painted IN PLACE on ``image`` (the reference's supervision BoxAnnotator also
+    paints on the array it is given, Appendix B.14) and returned."""
+    H, Wd = image.shape[:2]
+    for x0, y0, x1, y1 in np.asarray(det.xyxy, dtype=np.float64).reshape(-1, 4):
+        xa, xb = int(max(0, min(Wd - 1, round(x0)))), int(max(0, min(Wd - 1, round(x1))))
+        ya, yb = int(max(0, min(H - 1, round(y0)))), int(max(0, min(H - 1, round(y1))))
+        if xb < xa or yb < ya:
+            continue
+        image[ya, xa:xb + 1] = color
+        image[yb, xa:xb + 1] = color
+        image[ya:yb + 1, xa] = color
+        image[ya:yb + 1, xb] = color
+    return image
+
+
+def initialize_heuristic(heuristic_type: str = "owl-vit", **kwargs) -> HeuristicInterface:
+    """Factory with the reference's signature (TStarFramework.py:171-187)."""
+    if heuristic_type == "owl-vit":
+        return OWLInterface(model_name_or_path="google/owlvit-base-patch32", **kwargs)
+    raise NotImplementedError(f"Heuristic type '{heuristic_type}' is not implemented.")

@@ -1,0 +1,435 @@
+"""``TStarSearcher`` with the reference's constructor, attributes and ``search()`` contract
+(/root/reference/TStar/interface_searcher.py:14-538), running on one MI355X:
+
+* frames live in HBM (tstar_amd.video.FrameStore); gather + the cv2-style resizes + grid tiling
+  are one HIP kernel (tstar_frames_to_grid), verification frames another (tstar_frames_resize);
+* grid scoring and the detection -> grid-cell aggregation are tstar_owl_score;
+* the float64 searcher state (score_distribution, non_visiting_frames, P) lives on the device and
+  is updated by the tstar_searcher_* kernels; only the FITPACK smoothing-spline *fit*
+  (scipy.interpolate.UnivariateSpline, as the reference, :265) and the MT19937 draws
+  (numpy legacy RandomState, as the reference's np.random.choice, :353,372) run on the host;
+* verification (:382-420) is batched speculatively: every candidate frame of an iteration is
+  scored in one launch, then the reference's sequential ``remaining_targets`` logic is replayed on
+  the host, so results are identical to the one-call-per-frame loop.
+
+Behavioural quirks of the reference that callers can observe are kept:
+blank query, 0.005 threshold, verification overwriting ``score_distribution``, the sampler's
+fallback branch, weighted-random (not top-k) final keyframes, ``Score_history``-based first
+iteration, budget overshoot.  ``search_with_visualization`` is ``search`` (:493-538).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .video import FrameStore, open_video
+
+CELL_W, CELL_H = 200, 95            # create_image_grid's hard-coded cell size (:186)
+VERIFY_W, VERIFY_H = 200 * 3, 95 * 3  # verify_and_remove_target's resize (:403)
+
+
+class _DeviceState:
+    """ctypes wrapper of the tstar_searcher_* entry points."""
+
+    def __init__(self, n_frames: int, init_score: float, init_p: float):
+        self.lib = _lib.load()
+        self.N = n_frames
+        h = C.c_void_p()
+        _lib.check(self.lib.tstar_searcher_create(C.byref(h), n_frames, init_score, init_p), "tstar_searcher_create")
+        self.h = h
+        self._vx = np.empty(n_frames + 16, dtype=np.int32)
+        self._vy = np.empty(n_frames + 16, dtype=np.float64)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tstar_searcher_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def apply_grid(self, secs, d_conf) -> Tuple[np.ndarray, np.ndarray]:
+        s = np.ascontiguousarray(secs, dtype=np.int32)
+        nv = C.c_int(0)
+        _lib.check(self.lib.tstar_searcher_apply_grid(self.h, s.ctypes.data, d_conf.data_ptr(), len(s), C.byref(nv),
+                                                      self._vx.ctypes.data, self._vy.ctypes.data, _lib.stream_ptr()),
+                   "tstar_searcher_apply_grid")
+        return self._vx[:nv.value].copy(), self._vy[:nv.value].copy()
+
+    def set_spline(self, t, c, k):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        if len(c) < len(t):
+            c = np.concatenate([c, np.zeros(len(t) - len(c))])
+        _lib.check(self.lib.tstar_searcher_set_spline(self.h, t.ctypes.data, c.ctypes.data, len(t), int(k),
+                                                      _lib.stream_ptr()), "tstar_searcher_set_spline")
+
+    def sampler_prep(self, num: int, add: float) -> bool:
+        fb = C.c_int(0)
+        _lib.check(self.lib.tstar_searcher_sampler_prep(self.h, num, add, C.byref(fb), _lib.stream_ptr()),
+                   "tstar_searcher_sampler_prep")
+        return bool(fb.value)
+
+    def pop_prep(self):
+        _lib.check(self.lib.tstar_searcher_pop_prep(self.h, _lib.stream_ptr()), "tstar_searcher_pop_prep")
+
+    def draw(self, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty(len(x), dtype=np.int32)
+        _lib.check(self.lib.tstar_searcher_draw(self.h, x.ctypes.data, len(x), out.ctypes.data, _lib.stream_ptr()),
+                   "tstar_searcher_draw")
+        return out
+
+    def exclude(self, found):
+        f = np.ascontiguousarray(found, dtype=np.int32)
+        _lib.check(self.lib.tstar_searcher_exclude(self.h, f.ctypes.data, len(f), _lib.stream_ptr()),
+                   "tstar_searcher_exclude")
+
+    def set_scores(self, secs, vals):
+        s = np.ascontiguousarray(secs, dtype=np.int32)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        _lib.check(self.lib.tstar_searcher_set_scores(self.h, s.ctypes.data, v.ctypes.data, len(s), _lib.stream_ptr()),
+                   "tstar_searcher_set_scores")
+
+    def read(self, which: int) -> np.ndarray:
+        out = np.empty(self.N, dtype=np.float64)
+        _lib.check(self.lib.tstar_searcher_read(self.h, which, out.ctypes.data, _lib.stream_ptr()), "tstar_searcher_read")
+        return out
+
+
+class TStarSearcher:
+    """Keyframe search by object detection and dynamic sampling (drop-in for the reference class)."""
+
+    def __init__(
+        self,
+        video_path,
+        heuristic,
+        target_objects: List[str],
+        cue_objects: List[str],
+        search_nframes: int = 8,
+        image_grid_shape: Tuple[int, int] = (8, 8),
+        search_budget: float = 0.1,
+        output_dir: Optional[str] = None,
+        confidence_threshold: float = 0.5,
+        object2weight: Optional[dict] = None,
+        *,
+        rng: Optional[np.random.RandomState] = None,
+        keep_visual_history: bool = True,
+    ):
+        """Arguments as the reference (:21-48).  ``video_path`` may also be a FrameStore or a
+        ``synthetic://`` URL.  Extra keyword-only arguments: ``rng`` (a seeded legacy
+        ``RandomState``; default = the process-global numpy generator the reference draws from)
+        and ``keep_visual_history`` (False skips the device->host copies that only feed the
+        visualisation attributes)."""
+        self.video_path = video_path
+        self.target_objects = target_objects
+        self.cue_objects = cue_objects
+        self.search_nframes = search_nframes
+        self.image_grid_shape = image_grid_shape
+        self.output_dir = output_dir
+        self.confidence_threshold = confidence_threshold
+        self.object2weight = object2weight if object2weight else {}
+        self.fps = 1
+
+        self.store: FrameStore = open_video(video_path)       # ValueError("Cannot open video file...") as :61-62
+        self.raw_fps = self.store.raw_fps
+        total_frames = int(self.store.raw_total_frames)
+        self.duration = total_frames / self.raw_fps
+        self.total_frame_num = int(self.duration * self.fps)
+        if self.total_frame_num > self.store.num_seconds:
+            raise ValueError("FrameStore holds fewer frames than duration * fps")
+        self.remaining_targets = target_objects.copy()
+        self.search_budget = min(1000, self.total_frame_num * search_budget)
+
+        self._state = _DeviceState(self.total_frame_num, 1e-6, confidence_threshold * 0.3)
+        self.P_history = []
+        self.Score_history = []
+        self.non_visiting_history = []
+        self.image_grid_iters = []
+        self.detect_annotot_iters = []
+        self.detect_bbox_iters = []
+
+        self.heuristic = heuristic
+        self.heuristic.reparameterize_object_list(target_objects, cue_objects)
+        for obj in target_objects:
+            self.object2weight[obj] = 1.0
+        for obj in cue_objects:
+            self.object2weight[obj] = 0.5
+        self._fast = hasattr(heuristic, "score_batch") and hasattr(heuristic, "set_class_weights")
+        if self._fast:
+            heuristic.set_class_weights(self.object2weight)
+
+        self._rng = rng
+        self.keep_visual_history = keep_visual_history
+        self.frames_scored = 0        # g*g per grid call + 1 per verification call (BASELINE metric)
+        self.detector_calls = 0       # calls the reference would have made
+        self.device_images_scored = 0  # detector images actually pushed through the GPU
+        self.iterations = 0
+
+    # ---- state views (numpy copies of the device arrays, like the reference's attributes) -----
+    @property
+    def score_distribution(self) -> np.ndarray:
+        return self._state.read(0)
+
+    @property
+    def non_visiting_frames(self) -> np.ndarray:
+        return self._state.read(1)
+
+    @property
+    def P(self) -> np.ndarray:
+        return self._state.read(2)
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _uniform(self, k: int) -> np.ndarray:
+        return (self._rng if self._rng is not None else np.random).random_sample(k)
+
+    def _choice(self, size: int) -> np.ndarray:
+        """numpy legacy RandomState.choice(N, size, replace=False, p) over the device cdf
+        (:353-358, :372): MT19937 doubles on the host, searchsorted on the device."""
+        found: List[int] = []
+        while len(found) < size:
+            x = self._uniform(size - len(found))
+            if found:
+                self._state.exclude(found)
+            new = self._state.draw(x)
+            _, first = np.unique(new, return_index=True)
+            first.sort()
+            found.extend(int(v) for v in new.take(first))
+        return np.asarray(found[:size], dtype=np.int64)
+
+    def _names_from_mask(self, mask: int) -> List[str]:
+        return [self.heuristic.texts[q][0] for q in range(len(self.heuristic.texts)) if (mask >> q) & 1]
+
+    def _d_idx(self, secs):
+        import torch
+        return torch.as_tensor([int(s) for s in secs], dtype=torch.int32, device=self.store.frames.device)
+
+    # ---- detection -------------------------------------------------------------------------------
+    def imageGridScoreFunction(self, images: List[np.ndarray], output_dir: Optional[str], image_grids: Tuple[int, int]):
+        """Generic (host-image) path with the reference's signature and return types (:94-155):
+        one detector call per image through ``heuristic.inference_detector``."""
+        if not images:
+            return np.array([]), []
+        grid_rows, grid_cols = image_grids
+        grid_height = images[0].shape[0] / grid_rows
+        grid_width = images[0].shape[1] / grid_cols
+        conf_maps, name_maps = [], []
+        for image in images:
+            detections = self.heuristic.inference_detector(images=[image], use_amp=False)
+            cmap = np.zeros((grid_rows, grid_cols))
+            nmap: List[List[str]] = [[] for _ in range(grid_rows * grid_cols)]
+            for det in detections:
+                for box, label, conf in zip(det.xyxy, det.class_id, det.confidence):
+                    name = self.heuristic.texts[label][0]
+                    adj = conf * self.object2weight.get(name, 0.5)
+                    gx = min(int(((box[0] + box[2]) / 2) // grid_width), grid_cols - 1)
+                    gy = min(int(((box[1] + box[3]) / 2) // grid_height), grid_rows - 1)
+                    cmap[gy, gx] = max(cmap[gy, gx], adj)
+                    nmap[gy * grid_cols + gx].append(name)
+            conf_maps.append(cmap)
+            name_maps.append(nmap)
+        return np.stack(conf_maps), name_maps
+
+    def score_image_grids(self, images, image_grids):
+        return self.imageGridScoreFunction(images, self.output_dir, image_grids)
+
+    def read_frame_batch(self, video_path, frame_indices):
+        """(:157-169) native-resolution frames by RAW frame index (floats accepted, as pop_frames
+        passes them); the store is indexed by logical second, raw index i = int(sec * raw_fps)."""
+        last = self.store.num_seconds - 1
+        secs = [min(last, max(0, int(round(float(i) / self.raw_fps * self.fps)))) for i in frame_indices]
+        return frame_indices, self.store.host_frames(secs)
+
+    def create_image_grid(self, frames: List[np.ndarray], rows: int, cols: int):
+        raise NotImplementedError("grid images are built on the device by tstar_frames_to_grid; "
+                                  "use TStarSearcher._device_grid(secs)")
+
+    def _device_grid(self, secs):
+        import torch
+        rows, cols = self.image_grid_shape
+        if len(secs) != rows * cols:
+            raise ValueError("Frame count does not match grid dimensions")      # :183-184
+        N, H, Wd, _ = self.store.shape
+        grid = torch.empty((rows * CELL_H, cols * CELL_W, 3), dtype=torch.uint8, device=self.store.frames.device)
+        idx = self._d_idx(secs)
+        _lib.check(self._state.lib.tstar_frames_to_grid(self.store.frames.data_ptr(), N, H, Wd, idx.data_ptr(), rows,
+                                                        cols, grid.data_ptr(), _lib.stream_ptr()), "tstar_frames_to_grid")
+        return grid
+
+    def _device_verify_frames(self, secs):
+        import torch
+        N, H, Wd, _ = self.store.shape
+        out = torch.empty((len(secs), VERIFY_H, VERIFY_W, 3), dtype=torch.uint8, device=self.store.frames.device)
+        idx = self._d_idx(secs)
+        _lib.check(self._state.lib.tstar_frames_resize(self.store.frames.data_ptr(), N, H, Wd, idx.data_ptr(), len(secs),
+                                                       VERIFY_W, VERIFY_H, out.data_ptr(), _lib.stream_ptr()),
+                   "tstar_frames_resize")
+        return out
+
+    # ---- distribution ----------------------------------------------------------------------------
+    def store_score_distribution(self):
+        self.P_history.append(self._state.read(2).tolist())
+        self.Score_history.append(self._state.read(0).tolist())
+        self.non_visiting_history.append(self._state.read(1).tolist())
+
+    def _update_from_device(self, secs: List[int], d_conf):
+        """update_frame_distribution (:276-321) on the device state; d_conf f64 [rows*cols] (cell i <-> sample i)."""
+        from scipy.interpolate import UnivariateSpline
+        vx, vy = self._state.apply_grid(secs, d_conf)
+        spline = UnivariateSpline(vx, vy, s=0.5)                  # FITPACK fit on the host, as :265
+        t, c, k = spline._eval_args
+        self._state.set_spline(t, c, k)
+        self.store_score_distribution()
+
+    # ---- sampling --------------------------------------------------------------------------------
+    def sample_frames(self, num_samples: int):
+        """(:324-363) returns (seconds in draw order, device grid-ready frame indices).  The resized
+        frames themselves are produced on the device by ``_device_grid``."""
+        if num_samples > self.total_frame_num:
+            num_samples = self.total_frame_num
+        if not self.Score_history:
+            interval = self.total_frame_num // num_samples
+            secs = np.arange(0, self.total_frame_num, interval)[:num_samples]
+            if len(secs) < num_samples:
+                secs = np.append(secs, self.total_frame_num - 1)
+        else:
+            if self._state.sampler_prep(num_samples, num_samples / self.total_frame_num):
+                print("Warning: Not enough non-zero entries, adjusting probability distribution.")
+            secs = self._choice(num_samples)
+        return [int(s) for s in secs]
+
+    def pop_frames(self, video_path, num_samples: int):
+        """(:365-380) weighted random sample of K seconds from score_distribution, sorted."""
+        self._state.pop_prep()
+        secs = self._choice(num_samples)
+        secs.sort()
+        time_stamps = [sec / self.fps for sec in secs]
+        frames = self.store.host_frames(secs)
+        return frames, time_stamps
+
+    # ---- search ----------------------------------------------------------------------------------
+    def _verify_batch(self, secs: List[int], names_per_frame: List[List[str]]):
+        """verify_and_remove_target for every sampled frame of the iteration (:481-486, :382-420)."""
+        cands = [i for i, names in enumerate(names_per_frame) if any(t in names for t in self.remaining_targets)]
+        if not cands:
+            return
+        vframes = self._device_verify_frames([secs[i] for i in cands])
+        res = self.heuristic.score_batch(vframes, 1, 1)
+        self.device_images_scored += len(cands)
+        vconf = res.cell_conf[:, 0].cpu().numpy()
+        vmask = res.cell_mask[:, 0].cpu().numpy().astype(np.uint32)
+        slot = {i: j for j, i in enumerate(cands)}
+        upd_s, upd_v = [], []
+        for i, (sec, names) in enumerate(zip(secs, names_per_frame)):
+            for target in list(self.remaining_targets):
+                if target in names:
+                    j = slot[i]
+                    single_conf = vconf[j]
+                    single_names = self._names_from_mask(int(vmask[j]))
+                    upd_s.append(sec)
+                    upd_v.append(single_conf)
+                    self.frames_scored += 1
+                    self.detector_calls += 1
+                    if self.keep_visual_history:
+                        frame = vframes[j].cpu().numpy()
+                        det = self.heuristic._detections_from(res, j)
+                        self.image_grid_iters.append([frame])
+                        self.detect_annotot_iters.append(self.heuristic.bbox_visualization([frame], [det]))
+                        self.detect_bbox_iters.append([det])
+                    if target in single_names and single_conf > self.confidence_threshold:
+                        self.remaining_targets.remove(target)
+                        print(f"Found target '{target}' in frame {int(sec * self.raw_fps / self.fps)}, score {single_conf:.2f}")
+                        break
+        if upd_s:
+            self._state.set_scores(upd_s, upd_v)
+
+    def _verify_generic(self, secs, names_per_frame):
+        for sec, names in zip(secs, names_per_frame):
+            for target in list(self.remaining_targets):
+                if target in names:
+                    frame = self._device_verify_frames([sec])[0].cpu().numpy()
+                    conf_map, det_map = self.score_image_grids([frame], (1, 1))
+                    single_conf = conf_map[0, 0, 0]
+                    self._state.set_scores([sec], [single_conf])
+                    self.frames_scored += 1
+                    self.detector_calls += 1
+                    self.device_images_scored += 1
+                    if self.keep_visual_history:
+                        self.image_grid_iters.append([frame])
+                        self.detect_annotot_iters.append(self.heuristic.bbox_visualization(
+                            images=[frame], detections_inbatch=self.heuristic.detections_inbatch))
+                        self.detect_bbox_iters.append(self.heuristic.detections_inbatch)
+                    if target in det_map[0][0] and single_conf > self.confidence_threshold:
+                        self.remaining_targets.remove(target)
+                        print(f"Found target '{target}' in frame {int(sec * self.raw_fps / self.fps)}, score {single_conf:.2f}")
+                        break
+
+    def search(self):
+        """(:444-491) returns (keyframes uint8 [K,H,W,3], time_stamps list[float])."""
+        import torch
+        while self.remaining_targets and self.search_budget > 0:
+            rows, cols = self.image_grid_shape
+            n = rows * cols
+            secs = self.sample_frames(n)
+            self.search_budget -= n
+            grid = self._device_grid(secs)
+            if self._fast:
+                res = self.heuristic.score_batch(grid.unsqueeze(0), rows, cols)
+                self.device_images_scored += 1
+                d_conf = res.cell_conf[0]
+                masks = res.cell_mask[0].cpu().numpy().astype(np.uint32)
+                names_per_frame = [self._names_from_mask(int(m)) for m in masks[:len(secs)]]
+                if self.keep_visual_history:
+                    g = grid.cpu().numpy()
+                    det = self.heuristic._detections_from(res, 0)
+                    self.heuristic.detections_inbatch = [det]
+                    self.image_grid_iters.append([g])
+                    self.detect_annotot_iters.append(self.heuristic.bbox_visualization([g], [det]))
+                    self.detect_bbox_iters.append([det])
+            else:
+                g = grid.cpu().numpy()
+                conf_maps, name_maps = self.score_image_grids([g], self.image_grid_shape)
+                self.device_images_scored += 1
+                d_conf = torch.from_numpy(np.ascontiguousarray(conf_maps[0].reshape(-1))).to(grid.device)
+                names_per_frame = [name_maps[0][i] for i in range(len(secs))]
+                if self.keep_visual_history:
+                    self.image_grid_iters.append([g])
+                    self.detect_annotot_iters.append(self.heuristic.bbox_visualization(
+                        images=[g], detections_inbatch=self.heuristic.detections_inbatch))
+                    self.detect_bbox_iters.append(self.heuristic.detections_inbatch)
+            self.frames_scored += n
+            self.detector_calls += 1
+            self._update_from_device(secs, d_conf)
+            if self._fast:
+                self._verify_batch(secs, names_per_frame)
+            else:
+                self._verify_generic(secs, names_per_frame)
+            self.iterations += 1
+        return self.pop_frames(video_path=self.video_path, num_samples=self.search_nframes)
+
+    search_with_visualization = search
+
+    def plot_score_distribution(self, save_path: Optional[str] = None):
+        """(:423-441)"""
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        score = self.score_distribution
+        time_axis = np.linspace(0, self.duration, len(score))
+        plt.figure(figsize=(12, 6))
+        plt.plot(time_axis, score, label="Score Distribution")
+        plt.xlabel("Time (seconds)")
+        plt.ylabel("Score")
+        plt.title("Score Distribution Over Time")
+        plt.grid(True)
+        plt.legend()
+        if save_path:
+            plt.savefig(save_path, format="png", dpi=300)
+            print(f"Plot saved to {save_path}")
+        plt.close()

@@ -1,0 +1,165 @@
+"""Decoded-frame store resident in HBM.
+
+The reference re-opens the file with decord on every read
+(/root/reference/TStar/interface_searcher.py:157-169) and asks OpenCV for fps /
+frame count (:60-65).  Here a video is decoded ONCE into a uint8 tensor
+[N,H,W,3] (RGB) on the GPU and every later gather/resize is a HIP kernel
+(tstar_frames_to_grid / tstar_frames_resize).  Decode itself (FFmpeg/VCN) is
+outside the hot path (SURVEY.md 8f "next" row 3); real files need decord or cv2
+on the host, synthetic videos need nothing.
+"""
+from __future__ import annotations
+
+import re
+from typing import Optional
+
+import numpy as np
+
+
+def synthetic_lowres(n_frames: int, seed: int = 0) -> np.ndarray:
+    """uint8 [N,10,17,3] noise lattice, one frozen RandomState stream."""
+    return np.random.RandomState(seed).randint(0, 256, size=(n_frames, 10, 17, 3)).astype(np.uint8)
+
+
+def _planted(n_frames: int, seed: int):
+    """Seeded 5 % of frames get 1-2 solid rectangles: (frame, y0, y1, x0, x1, rgb) in 9x16 lattice units."""
+    rs = np.random.RandomState(seed + 1)
+    frames = np.nonzero(rs.random_sample(n_frames) < 0.05)[0]
+    out = []
+    for f in frames:
+        for _ in range(1 + int(rs.randint(0, 2))):
+            y0, x0 = int(rs.randint(0, 7)), int(rs.randint(0, 13))
+            h, w = int(rs.randint(2, 4)), int(rs.randint(2, 5))
+            rgb = tuple(int(v) for v in rs.randint(0, 256, 3))
+            out.append((int(f), y0, min(y0 + h, 9), x0, min(x0 + w, 16), rgb))
+    return out
+
+
+def synthetic_frames_numpy(idx, n_frames: int, H: int = 360, W: int = 640, seed: int = 0) -> np.ndarray:
+    """CPU statement of the synthetic video (integer arithmetic only): frames ``idx`` as uint8 [n,H,W,3].
+
+    Frame = integer bilinear upsampling of the 10x17 lattice (cell size H/9 x W/16)
+    + planted rectangles.  ``synthetic_video`` computes the same bytes on the GPU.
+    """
+    low = synthetic_lowres(n_frames, seed).astype(np.int64)
+    cy, cx = H // 9, W // 16
+    ys, xs = np.arange(H), np.arange(W)
+    y0, fy = ys // cy, ys % cy
+    x0, fx = xs // cx, xs % cx
+    out = np.empty((len(idx), H, W, 3), dtype=np.uint8)
+    rects = _planted(n_frames, seed)
+    for k, i in enumerate(idx):
+        L = low[int(i)]
+        a = L[y0][:, x0] * ((cy - fy)[:, None, None] * (cx - fx)[None, :, None])
+        b = L[y0][:, x0 + 1] * ((cy - fy)[:, None, None] * fx[None, :, None])
+        c = L[y0 + 1][:, x0] * (fy[:, None, None] * (cx - fx)[None, :, None])
+        d = L[y0 + 1][:, x0 + 1] * (fy[:, None, None] * fx[None, :, None])
+        fr = ((a + b + c + d) // (cy * cx)).astype(np.uint8)
+        for (f, ry0, ry1, rx0, rx1, rgb) in rects:
+            if f == int(i):
+                fr[ry0 * cy:ry1 * cy, rx0 * cx:rx1 * cx] = rgb
+        out[k] = fr
+    return out
+
+
+class FrameStore:
+    """A decoded video in HBM at the searcher's logical rate (1 frame per second):
+    ``frames`` uint8 cuda tensor [N,H,W,3] with frames[s] = raw frame int(s * raw_fps)
+    (the index map of interface_searcher.py:360), plus the raw stream's fps / frame count."""
+
+    def __init__(self, frames, raw_fps: float, raw_total_frames: Optional[int] = None, name: str = "<frames>"):
+        self.frames = frames
+        self.raw_fps = float(raw_fps)
+        self.raw_total_frames = int(raw_total_frames if raw_total_frames is not None
+                                    else round(frames.shape[0] * self.raw_fps))
+        self.name = name
+
+    @property
+    def num_seconds(self) -> int:
+        return int(self.frames.shape[0])
+
+    @property
+    def shape(self):
+        return tuple(self.frames.shape)
+
+    def host_frames(self, secs) -> np.ndarray:
+        """Native-resolution frames of the given logical seconds -> uint8 numpy [n,H,W,3]."""
+        import torch
+        ii = torch.as_tensor([int(i) for i in secs], dtype=torch.long, device=self.frames.device)
+        return self.frames.index_select(0, ii).cpu().numpy()
+
+
+def synthetic_video(n_frames: int = 3600, H: int = 360, W: int = 640, seed: int = 0, raw_fps: float = 1.0,
+                    device: str = "cuda", chunk: int = 256) -> FrameStore:
+    """Build the synthetic video directly in HBM (torch integer ops = tensor plumbing; the
+    bytes equal ``synthetic_frames_numpy``)."""
+    import torch
+    if H % 9 or W % 16:
+        raise ValueError("synthetic video needs H % 9 == 0 and W % 16 == 0")
+    low = torch.from_numpy(synthetic_lowres(n_frames, seed)).to(device).to(torch.int32)
+    cy, cx = H // 9, W // 16
+    ys = torch.arange(H, device=device)
+    xs = torch.arange(W, device=device)
+    y0, fy = ys // cy, (ys % cy).to(torch.int32)
+    x0, fx = xs // cx, (xs % cx).to(torch.int32)
+    wy0, wy1 = (cy - fy)[None, :, None, None], fy[None, :, None, None]
+    wx0, wx1 = (cx - fx)[None, None, :, None], fx[None, None, :, None]
+    frames = torch.empty((n_frames, H, W, 3), dtype=torch.uint8, device=device)
+    for s in range(0, n_frames, chunk):
+        L = low[s:s + chunk]
+        top = L[:, y0]
+        bot = L[:, y0 + 1]
+        v = top[:, :, x0] * (wy0 * wx0) + top[:, :, x0 + 1] * (wy0 * wx1) \
+            + bot[:, :, x0] * (wy1 * wx0) + bot[:, :, x0 + 1] * (wy1 * wx1)
+        frames[s:s + chunk] = torch.div(v, cy * cx, rounding_mode="floor").to(torch.uint8)
+    for (f, ry0, ry1, rx0, rx1, rgb) in _planted(n_frames, seed):
+        frames[f, ry0 * cy:ry1 * cy, rx0 * cx:rx1 * cx] = torch.tensor(rgb, dtype=torch.uint8, device=device)
+    return FrameStore(frames, raw_fps, None, name=f"synthetic://n={n_frames},h={H},w={W},seed={seed}")
+
+
+_SYN = re.compile(r"^synthetic://")
+
+
+def open_video(video, device: str = "cuda") -> FrameStore:
+    """``video``: a FrameStore, a ``synthetic://n=..,h=..,w=..,seed=..,fps=..`` URL, or a file path
+    (decoded at native rate through decord, else cv2; both absent -> ValueError like the
+    reference's ``Cannot open video file`` at interface_searcher.py:61-62)."""
+    if isinstance(video, FrameStore):
+        return video
+    if isinstance(video, str) and _SYN.match(video):
+        kv = dict(p.split("=") for p in video[len("synthetic://"):].split(",") if p)
+        return synthetic_video(int(kv.get("n", 3600)), int(kv.get("h", 360)), int(kv.get("w", 640)),
+                               int(kv.get("seed", 0)), float(kv.get("fps", 1.0)), device)
+    import torch
+    try:
+        from decord import VideoReader, cpu  # type: ignore
+        vr = VideoReader(video, ctx=cpu(0))
+        fps = float(vr.get_avg_fps())
+        total = len(vr)
+        want = [int(sec * fps) for sec in range(int(total / fps))]
+        parts = [torch.from_numpy(vr.get_batch(want[s:s + 256]).asnumpy()).to(device)
+                 for s in range(0, len(want), 256)]
+        return FrameStore(torch.cat(parts), fps, total, name=video)
+    except ImportError:
+        pass
+    try:
+        import cv2  # type: ignore
+    except ImportError:
+        raise ValueError(f"Cannot open video file: {video} (neither decord nor cv2 is importable; "
+                         "pass a tstar_amd.video.FrameStore or a synthetic:// URL)")
+    cap = cv2.VideoCapture(video)
+    if not cap.isOpened():
+        raise ValueError(f"Cannot open video file: {video}")
+    fps = cap.get(cv2.CAP_PROP_FPS)
+    total = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+    want = {int(sec * fps) for sec in range(int(total / fps))}
+    out, i = [], 0
+    while True:
+        ok, fr = cap.read()
+        if not ok:
+            break
+        if i in want:
+            out.append(torch.from_numpy(fr[:, :, ::-1].copy()).to(device))
+        i += 1
+    cap.release()
+    return FrameStore(torch.stack(out), fps, total, name=video)
