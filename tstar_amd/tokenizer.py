@@ -32,7 +32,11 @@ def _hf_tokenizer(model_name_or_path: str):
         import os
         os.environ.setdefault("HF_HUB_OFFLINE", "1")
         from transformers import CLIPTokenizer
-        _HF_TOK = CLIPTokenizer.from_pretrained(model_name_or_path, local_files_only=True)
+        tok = CLIPTokenizer.from_pretrained(model_name_or_path, local_files_only=True)
+        # transformers can hand back an EMPTY tokenizer when no vocab is on disk: accept it only if
+        # it really is the CLIP BPE vocabulary (BOS 49406 / EOS 49407 around a known word)
+        probe = tok(["cat"], padding="max_length", max_length=TEXT_LEN, truncation=True)["input_ids"][0]
+        _HF_TOK = tok if (probe[0] == BOS and probe[2] == EOS and len(tok) >= 49408) else None
     except Exception:
         _HF_TOK = None
     return _HF_TOK
