@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- T* keyframe-search hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete keyframe search (TStarSearcher.search(): iterative sampling, grid
+scoring, verification, distribution updates, final K=8 keyframes) over one 3600-frame
+synthetic video that is already resident in HBM -- BASELINE.json configs[1]: "Same single
+video on 1xMI355X, HIP OWL-ViT-B/32 scorer, batch=256 frames/iter" (grid 16x16).  With N > 1
+(torch.distributed, one rank per GPU, RCCL) every rank searches its own stream of independent
+(video, question) items (weak scaling, no data-path collective) and the final keyframe indices
+are all-gathered once inside the timed region.
+
+Prints ONE JSON line on rank 0.  value = candidate frames scored / s over all ranks; a frame
+is scored each time it contributes a confidence to the searcher: g*g per grid call + 1 per
+verification call.  Weights are seeded synthetic OWL-ViT-B/32 (no checkpoint
+offline), data synthetic.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+N_FRAMES, FRAME_H, FRAME_W = 3600, 360, 640
+TARGETS, CUES = ["couch"], ["tv", "chair"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=16, help="grid side g (g*g frames per iteration)")
+    ap.add_argument("--max-batch", type=int, default=64, help="detector images per forward chunk")
+    ap.add_argument("--nframes", type=int, default=N_FRAMES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def run_search(heuristic, store, g, seed):
+    from tstar_amd.interface_searcher import TStarSearcher
+    s = TStarSearcher(store, heuristic, list(TARGETS), list(CUES), search_nframes=8, image_grid_shape=(g, g),
+                      search_budget=1000, confidence_threshold=0.6, rng=np.random.RandomState(seed),
+                      keep_visual_history=False)
+    _, ts = s.search()
+    return s, ts
+
+
+def cpu_baseline(args, stats):
+    """Reference-faithful CPU path (oracle = "port") on the host cores: one grid call and a few
+    verification calls are timed, then extrapolated to the GPU run's call mix."""
+    import torch
+    from oracle import cpu_pipeline, resize_ref
+    from tstar_amd import weights as W
+    from tstar_amd.tokenizer import encode_queries
+    from tstar_amd.video import synthetic_frames_numpy
+    g = args.grid
+    det = cpu_pipeline.CpuOwlDetector(W.synthetic_state_dict(0), faithful=True)
+    texts = [[o] for o in TARGETS + CUES] + [[" "]]
+    ids, am = encode_queries(texts)
+    det.reparameterize_object_list(TARGETS, CUES, ids, am)
+    o2w = {**{t: 1.0 for t in TARGETS}, **{c: 0.5 for c in CUES}}
+    n = g * g
+    secs = list(np.arange(0, args.nframes, args.nframes // n)[:n])
+    frames = synthetic_frames_numpy(secs, args.nframes, FRAME_H, FRAME_W, seed=0)    # "decoded" frames, untimed
+    fn = cpu_pipeline.make_score_fn(det, lambda s: frames[[secs.index(int(x)) for x in s]], o2w)
+    t0 = time.perf_counter()
+    fn("grid", secs, g, g)
+    t_grid = time.perf_counter() - t0
+    nv, t_ver = 0, 0.0
+    deadline = time.perf_counter() + max(1.0, args.cpu_seconds - t_grid)
+    while nv < 64 and time.perf_counter() < deadline:
+        t0 = time.perf_counter()
+        fn("verify", [secs[nv]], 1, 1)
+        t_ver += time.perf_counter() - t0
+        nv += 1
+    t_ver /= max(nv, 1)
+    per_video = stats["grid_calls"] * t_grid + stats["verify_calls"] * t_ver
+    frames_scored = stats["grid_calls"] * n + stats["verify_calls"]
+    return {
+        "value": frames_scored / per_video, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"1 grid call ({n} frames, {t_grid:.3f} s) + {nv} verification calls ({t_ver:.3f} s each) of the same "
+                  f"workload, reference-faithful (text tower per call, batch-1 verification), extrapolated to the GPU "
+                  f"run's call mix ({stats['grid_calls']} grid + {stats['verify_calls']} verification calls per video)",
+        "sec_per_video": per_video,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from tstar_amd import _lib
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.sharding import gather_keyframes
+    from tstar_amd.video import synthetic_video
+    lib = _lib.load()
+
+    heuristic = OWLInterface(synthetic_seed=0, max_batch=args.max_batch, device=f"cuda:{local_rank}")
+    store = synthetic_video(args.nframes, FRAME_H, FRAME_W, seed=0)
+    g = args.grid
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        run_search(heuristic, store, g, 10_000 + rank * 1000 + w)
+    barrier()
+    _lib.check(lib.tstar_prof_enable(1))
+    t0 = time.perf_counter()
+    frames = grid_calls = verify_calls = images = 0
+    keys = []
+    for k in range(args.steps):
+        s, ts = run_search(heuristic, store, g, 2025 + rank * args.steps + k)
+        frames += s.frames_scored
+        grid_calls += s.iterations
+        verify_calls += s.detector_calls - s.iterations
+        images += s.device_images_scored
+        keys.append([int(t) for t in ts])
+    all_keys = gather_keyframes(keys, world)            # RCCL all-gather of the keyframe indices (N > 1)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(frames), float(images)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, frames_all, images_all = tmax[0].item(), t[1].item(), t[2].item()
+    else:
+        frames_all, images_all = float(frames), float(images)
+
+    # roofline of the dominant kernel (gemm_f32_kernel): HIP events on the launch stream, this rank
+    n_l, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
+    _lib.check(lib.tstar_prof_read(0, C.byref(n_l), C.byref(ms), C.byref(fl)))
+    a_l, a_ms, a_fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
+    _lib.check(lib.tstar_prof_read(1, C.byref(a_l), C.byref(a_ms), C.byref(a_fl)))
+    _lib.check(lib.tstar_prof_enable(0))
+    achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "candidate frames scored/sec (whole node) + sec/video to 8 keyframes, 1h@1fps",
+            "value": frames_all / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: {args.nframes}-frame {FRAME_H}x{FRAME_W} synthetic RGB video resident in HBM, 1 question "
+                            f"(targets {TARGETS}, cues {CUES}), OWL-ViT-B/32 fp32 (seeded synthetic weights), grid {g}x{g} = "
+                            f"{g * g} frames/iter, search_nframes=8, threshold 0.6, budget 1000",
+                "sec_per_video": dt / args.steps, "videos_per_rank": args.steps,
+                "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,
+                "detector_images_per_video": images / args.steps, "max_batch": args.max_batch,
+                "keyframes_rank0_step0": keys[0], "gathered_keyframe_rows": len(all_keys),
+            },
+            "roofline": {
+                "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": achieved,
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches": n_l.value, "avg_launch_ms": ms.value / max(n_l.value, 1),
+                "avg_launch_gflop": fl.value / max(n_l.value, 1) / 1e9,
+                "time_share_of_step": ms.value * 1e-3 / dt,
+                "attention_f32_kernel": {"achieved": (a_fl.value / (a_ms.value * 1e-3) / 1e12) if a_ms.value > 0 else 0.0,
+                                         "launches": a_l.value, "time_share_of_step": a_ms.value * 1e-3 / dt},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, {"grid_calls": grid_calls / args.steps,
+                                                      "verify_calls": verify_calls / args.steps})
+            out["config"]["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,6 +152,12 @@ int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const fl
 int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode,
                         const uint8_t* d_key_mask, void* stream);
 
+/* Per-kernel timing with HIP events recorded on the launch stream, for bench.py's roofline leg.
+ * category 0 = gemm_f32_kernel, 1 = attention_f32_kernel.  enable(1) resets the counters;
+ * read() synchronises the recorded events and returns launches / total ms / total algorithmic flops. */
+int tstar_prof_enable(int on);
+int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@
 //    V read as ds_read_b32 rows (two 32-lane halves never conflict).
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 #include <math.h>
 
 namespace tstar {
@@ -178,10 +179,13 @@ int attention_f32(const float* qkv, float* out, int B, int T, int heads, int mod
     TSTAR_REQUIRE(mode == 0 || (mode == 1 && key_mask != nullptr), "attention_f32: mode 1 needs key_mask");
     const int qtiles = cdiv(T, 128);
     const int grid = B * heads * qtiles;
+    const bool prof = prof_enabled();
+    if (prof) prof_start(PROF_ATTN, s, 4.0 * B * heads * (double)T * T * HD);
     if (mode == 0)
         hipLaunchKernelGGL(attention_f32_kernel<0>, dim3(grid), dim3(256), 0, s, qkv, out, T, heads, qtiles, key_mask);
     else
         hipLaunchKernelGGL(attention_f32_kernel<1>, dim3(grid), dim3(256), 0, s, qkv, out, T, heads, qtiles, key_mask);
+    if (prof) prof_stop(PROF_ATTN, s);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
 }

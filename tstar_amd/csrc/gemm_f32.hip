@@ -25,6 +25,7 @@
 //    panel) land on the same XCD's L2.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace tstar {
 
@@ -164,7 +165,10 @@ static int launch_one(const GemmArgs& g, hipStream_t stream) {
         attr_set = true;
     }
     const int nwg = cdiv(g.M, BM) * (g.N / BN);
+    const bool prof = prof_enabled();
+    if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), GEMM_LDS_BYTES, stream, g);
+    if (prof) prof_stop(PROF_GEMM, stream);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
 }

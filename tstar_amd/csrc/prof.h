@@ -1,0 +1,11 @@
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+#pragma once
+#include "common.h"
+
+namespace tstar {
+enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_NCAT = 2 };
+bool prof_enabled();
+// record the start / stop events around one launch; `work` = algorithmic flops of the launch
+void prof_start(int cat, hipStream_t s, double work);
+void prof_stop(int cat, hipStream_t s);
+}  // namespace tstar

@@ -1,0 +1,57 @@
+// Event-pair profiler: when enabled, every GEMM / attention launch is bracketed by two
+// hipEvents on the stream it is launched on; tstar_prof_read() synchronises them and returns
+// per-category (launches, total ms, total algorithmic flops).  Disabled by default (zero cost).
+#include "../../include/tstar_hip.h"
+#include "prof.h"
+#include <vector>
+
+namespace tstar {
+struct Pair { hipEvent_t a, b; double work; };
+struct Cat { std::vector<Pair> pending; std::vector<Pair> pool; long launches = 0; double ms = 0, work = 0; };
+static Cat g_cat[PROF_NCAT];
+static bool g_on = false;
+
+bool prof_enabled() { return g_on; }
+
+static void drain(Cat& c) {
+    for (Pair& p : c.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c.ms += ms; c.work += p.work; c.launches += 1;
+        }
+        c.pool.push_back(p);
+    }
+    c.pending.clear();
+}
+
+void prof_start(int cat, hipStream_t s, double work) {
+    Cat& c = g_cat[cat];
+    if (c.pending.size() >= 16384) drain(c);
+    Pair p;
+    if (!c.pool.empty()) { p = c.pool.back(); c.pool.pop_back(); }
+    else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+    p.work = work;
+    (void)hipEventRecord(p.a, s);
+    c.pending.push_back(p);
+}
+
+void prof_stop(int cat, hipStream_t s) {
+    Cat& c = g_cat[cat];
+    if (!c.pending.empty()) (void)hipEventRecord(c.pending.back().b, s);
+}
+}  // namespace tstar
+
+using namespace tstar;
+extern "C" {
+int tstar_prof_enable(int on) {
+    g_on = on != 0;
+    for (int i = 0; i < PROF_NCAT; ++i) { drain(g_cat[i]); g_cat[i].launches = 0; g_cat[i].ms = 0; g_cat[i].work = 0; }
+    return TSTAR_OK;
+}
+int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops) {
+    TSTAR_REQUIRE(category >= 0 && category < PROF_NCAT && launches && total_ms && total_flops, "tstar_prof_read: bad argument");
+    drain(g_cat[category]);
+    *launches = g_cat[category].launches; *total_ms = g_cat[category].ms; *total_flops = g_cat[category].work;
+    return TSTAR_OK;
+}
+}

@@ -1,0 +1,79 @@
+"""Sharding of independent (video, question) items over the GPUs of one node.
+
+The reference's dataset runner is a sequential loop in one process
+(/root/reference/LVHaystackBench/run_TStar_onDataset.py:195-205).  Items are independent
+(a new searcher per item, :108,125; the heuristic's per-item state is reset by
+reparameterize_object_list), so the path shards with NO data-path collective: item i goes to
+rank i % world, every rank seeds its sampler per item (seed = base + item id, so results do
+not depend on the rank count), and ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU
+tests) collects the K keyframe indices of every item at the end -- about 1 KB for 32 videos,
+latency-bound.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import numpy as np
+
+
+def shard_items(n_items: int, world: int, rank: int) -> List[int]:
+    """Item ids of this rank (round robin; item cost is ~constant: the 1000-frame budget cap)."""
+    return list(range(rank, n_items, world))
+
+
+def item_seed(base_seed: int, item_id: int) -> int:
+    return int(base_seed) + int(item_id)
+
+
+def gather_keyframes(local_rows: Sequence[Sequence[int]], world: int, pad_to: int | None = None) -> List[List[int]]:
+    """All-gather int32 [rows_per_rank, K] (padded with -1) -> list of rows in rank-major order.
+
+    With world == 1 (or no initialised process group) this is the identity."""
+    rows = [list(map(int, r)) for r in local_rows]
+    if world <= 1:
+        return rows
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        raise RuntimeError("gather_keyframes: torch.distributed is not initialised")
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    k = max([len(r) for r in rows], default=0)
+    shape = torch.tensor([len(rows), k], dtype=torch.int64, device=dev)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+    nrow, k = int(shape[0]), int(shape[1])
+    if pad_to is not None:
+        nrow = max(nrow, pad_to)
+    buf = torch.full((nrow, k), -1, dtype=torch.int32, device=dev)
+    for i, r in enumerate(rows):
+        buf[i, :len(r)] = torch.tensor(r, dtype=torch.int32, device=dev)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    res: List[List[int]] = []
+    for t in out:
+        for row in t.cpu().numpy():
+            if (row >= 0).any():
+                res.append([int(v) for v in row if v >= 0])
+    return res
+
+
+def interleave_by_item(gathered: List[List[int]], n_items: int, world: int) -> List[List[int]]:
+    """Undo the rank-major order of gather_keyframes for a round-robin sharding: result[i] = item i."""
+    per_rank = [len(shard_items(n_items, world, r)) for r in range(world)]
+    out: List[List[int]] = [[] for _ in range(n_items)]
+    pos = 0
+    for r in range(world):
+        for j in range(per_rank[r]):
+            out[r + j * world] = gathered[pos]
+            pos += 1
+    return out
+
+
+def run_sharded(n_items: int, search_item: Callable[[int], Sequence[int]], world: int, rank: int) -> List[List[int]]:
+    """Run ``search_item(item_id) -> keyframe indices`` for this rank's items, gather all results,
+    and return them ordered by item id (identical on every rank)."""
+    mine = [list(search_item(i)) for i in shard_items(n_items, world, rank)]
+    gathered = gather_keyframes(mine, world, pad_to=(n_items + world - 1) // world)
+    if world <= 1:
+        return gathered
+    return interleave_by_item(gathered, n_items, world)
