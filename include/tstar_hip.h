@@ -70,6 +70,9 @@ int tstar_owl_set_queries(tstar_owl* h, const int32_t* h_input_ids, const int32_
 /* Same, from precomputed L2-normalised embeddings float32 [Q,512] and query mask u8 [Q]. */
 int tstar_owl_set_query_embeds(tstar_owl* h, const float* h_query_embeds, const uint8_t* h_query_mask,
                                const float* h_class_weight, int Q, void* stream);
+/* Replaces only the per-query class weights (TStarSearcher sets object2weight AFTER it has
+ * reparameterised the heuristic, interface_searcher.py:87-91). */
+int tstar_owl_set_class_weights(tstar_owl* h, const float* h_class_weight, int Q, void* stream);
 /* Copies the resident (L2-normalised, pre-class-head) query embeddings float32 [Q,512] to the host. */
 int tstar_owl_get_query_embeds(tstar_owl* h, float* h_out, int Q, void* stream);
 
@@ -147,6 +150,9 @@ int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* strea
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual); act: 0 none, 1 quick-gelu, 2 gelu(erf) */
 int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                    int M, int N, int K, int act, void* stream);
+/* same with the block tile forced: 0 = 128x128, 1 = 64x128, 2 = 64x64 (-1 = the launcher's choice) */
+int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
+                       int M, int N, int K, int act, int tile_cfg, void* stream);
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream);
 /* qkv [B*T, 3*heads*64] -> out [B*T, heads*64]; mode 0 full, 1 causal + key mask u8 [B,T] */
 int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode,

@@ -41,6 +41,23 @@ def test_gemm_bias_act(lib, M, N, K, act):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(577, 768, 3072), (130, 256, 64), (1154, 512, 768)])
+def test_gemm_tile_configs(lib, cfg, M, N, K):
+    """All three block-tile shapes compute the same product (the launcher picks per shape)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    ref = F.linear(A, W, b)
+    dA, dW, db = A.cuda(), W.cuda(), b.cuda()
+    dC = torch.full((M, N), float("nan"), device="cuda")
+    _check(lib.tstar_gemm_f32_cfg(dA.data_ptr(), dW.data_ptr(), dC.data_ptr(), db.data_ptr(), None, M, N, K, 0, cfg,
+                                  torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert (dC.cpu() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_gemm_asymmetric_identity(lib):
     """A = I against an asymmetric W: catches row/col swaps in the C/D layout."""
     N = K = 128

@@ -1,0 +1,172 @@
+// Kernel lab (not part of the library): variants of the fp32 MFMA GEMM main loop, timed standalone.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <math.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8; int xcd = bid % nx, idx = bid / nx; int q = nwg / nx, r = nwg % nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q; return base + idx;
+}
+
+// pure MFMA ceiling
+__global__ __launch_bounds__(256) void mfma_only(float* out, int iters) {
+    f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    float x = threadIdx.x * 1e-3f, y = threadIdx.x * 2e-3f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+    float s = 0; for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// WM x WN waves, each wave TM x TN tiles of 32x32; BM = WM*TM*32, BN = WN*TN*32
+template <int WM, int WN, int TM, int TN, int BK, int MINW, bool PRIO>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_var(const float* __restrict__ A, const float* __restrict__ W,
+                                                               float* __restrict__ C, const float* __restrict__ bias,
+                                                               int M, int N, int K) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BK + 4, NT = WM * WN * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem; float* Bs = smem + 2 * BM * LD;
+    const int nt = N / BN, mt = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, h = lane >> 5;
+    constexpr int F4R = BK / 4;                 // float4 per row
+    constexpr int RPP = NT / F4R;               // rows per pass
+    constexpr int NA = BM / RPP, NB = BN / RPP;
+    const int c4 = t % F4R, r0 = t / F4R;
+    const float* ap[NA]; const float* bp[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { int ar = m0 + r0 + RPP * i; ar = ar < M ? ar : M - 1; ap[i] = A + (size_t)ar * K + c4 * 4; }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bp[i] = W + (size_t)(n0 + r0 + RPP * i) * K + c4 * 4;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[NA], rb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + RPP * i) * LD + c4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + RPP * i) * LD + c4 * 4]) = rb[i];
+    __syncthreads();
+    const int nk = K / BK; int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * BK);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + (kt + 1) * BK);
+        }
+        const float* Ac = As + cur * BM * LD + (wm * TM * 32 + l31) * LD + h * 4;
+        const float* Bc = Bs + cur * BN * LD + (wn * TN * 32 + l31) * LD + h * 4;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LD + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (more) {
+            float* Aw = As + (cur ^ 1) * BM * LD; float* Bw = Bs + (cur ^ 1) * BN * LD;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&Aw[(r0 + RPP * i) * LD + c4 * 4]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bw[(r0 + RPP * i) * LD + c4 * 4]) = rb[i];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r] + bv;
+            }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int MINW, bool PRIO>
+float run(const char* name, const float* A, const float* W, float* C, const float* bias, int M, int N, int K, int iters) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BK + 4;
+    const int lds = 2 * (BM + BN) * LD * 4;
+    auto k = gemm_var<WM, WN, TM, TN, BK, MINW, PRIO>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int nwg = ((M + BM - 1) / BM) * (N / BN);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(WM * WN * 64), lds, 0, A, W, C, bias, M, N, K);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(WM * WN * 64), lds, 0, A, W, C, bias, M, N, K);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    printf("%-28s M=%6d N=%5d K=%5d lds=%6d nwg=%5d  %8.3f ms %7.1f TF\n", name, M, N, K, lds, nwg, ms, 2.0 * M * N * K / ms / 1e9);
+    return ms;
+}
+
+int main() {
+    const int MMAX = 64 * 577, NMAX = 3072, KMAX = 3072;
+    float *A, *W, *C, *bias;
+    CK(hipMalloc(&A, (size_t)MMAX * KMAX * 4)); CK(hipMalloc(&W, (size_t)NMAX * KMAX * 4));
+    CK(hipMalloc(&C, (size_t)MMAX * NMAX * 4)); CK(hipMalloc(&bias, NMAX * 4));
+    std::vector<float> h((size_t)MMAX * KMAX);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+    CK(hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W, h.data(), (size_t)NMAX * KMAX * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, NMAX * 4));
+    {   // ceiling
+        float* o; CK(hipMalloc(&o, 256 * 8 * 256 * 4));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int wpb = 1; wpb <= 2; ++wpb) {
+            const int iters = 20000, blocks = 256 * wpb;
+            hipLaunchKernelGGL(mfma_only, dim3(blocks), dim3(256), 0, 0, o, 100);
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(mfma_only, dim3(blocks), dim3(256), 0, 0, o, iters);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("mfma_only %d blocks/CU: %.3f ms  %.1f TF\n", wpb, ms, (double)blocks * 4 * iters * 4 * 4096.0 / ms / 1e9);
+        }
+    }
+    struct Shape { int M, N, K; } shapes[] = {{9232, 768, 768}, {9232, 2304, 768}, {9232, 768, 3072}, {25388, 768, 768}, {25388, 2304, 768}, {25388, 768, 3072}, {36928, 768, 768}, {36928, 3072, 768}, {36928, 768, 3072}, {25344, 512, 768}, {577, 768, 768}, {577, 2304, 768}, {577, 768, 3072}, {2308, 768, 768}, {2308, 2304, 768}, {2308, 768, 3072}};
+    for (auto s : shapes) {
+        run<2, 2, 2, 2, 32, 2, true>("128x128x32 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 1, 2, 32, 3, true>("64x128x32 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 2, 1, 32, 3, true>("128x64x32 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 1, 1, 32, 4, true>("64x64x32 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 1, 1, 64, 2, true>("64x64x64 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<1, 4, 2, 1, 32, 3, true>("64x128x32 4w(1x4) prio", A, W, C, bias, s.M, s.N, s.K, 10);
+        printf("\n");
+    }
+    return 0;
+}

@@ -29,6 +29,7 @@ SIGNATURES = {
     "tstar_owl_destroy": (_i, [_vp]),
     "tstar_owl_set_queries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "tstar_owl_set_query_embeds": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "tstar_owl_set_class_weights": (_i, [_vp, _vp, _i, _vp]),
     "tstar_owl_get_query_embeds": (_i, [_vp, _vp, _i, _vp]),
     "tstar_owl_score": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tstar_owl_debug_preprocess": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -45,6 +46,7 @@ SIGNATURES = {
     "tstar_searcher_set_scores": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tstar_searcher_read": (_i, [_vp, _i, _vp, _vp]),
     "tstar_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tstar_gemm_f32_cfg": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tstar_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tstar_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tstar_prof_enable": (_i, [_i]),
@@ -63,6 +65,10 @@ def load() -> C.CDLL:
         raise TStarHipError(
             f"{LIB_PATH} is missing: build it with `python -m tstar_amd.build` "
             "(hipcc --offload-arch=gfx950). tstar_amd has no CPU fallback.")
+    # torch ships its own libamdhip64: import it FIRST so this library binds to the same HIP
+    # runtime (loading ours first pulls in /opt/rocm's copy and the two runtimes do not share
+    # devices or memory).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

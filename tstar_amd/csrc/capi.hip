@@ -121,7 +121,7 @@ static GemmArgs mk_gemm(const float* A, const float* W, float* C, const float* b
                         int K, int lda, int ldc, int act) {
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0; g.tile_cfg = -1;
     return g;
 }
 
@@ -274,6 +274,15 @@ int tstar_owl_set_query_embeds(tstar_owl* h, const float* h_qe, const uint8_t* h
     return finish_queries(h, h_mask, h_w, Q, s);
 }
 
+int tstar_owl_set_class_weights(tstar_owl* h, const float* h_w, int Q, void* stream) {
+    TSTAR_REQUIRE(h && h_w, "tstar_owl_set_class_weights: null argument");
+    TSTAR_REQUIRE(Q == h->Q && Q >= 1, "tstar_owl_set_class_weights: Q does not match the installed queries");
+    hipStream_t s = (hipStream_t)stream;
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight, h_w, Q * sizeof(float), hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(s));
+    return TSTAR_OK;
+}
+
 int tstar_owl_get_query_embeds(tstar_owl* h, float* h_out, int Q, void* stream) {
     TSTAR_REQUIRE(h && h_out, "tstar_owl_get_query_embeds: null argument");
     TSTAR_REQUIRE(Q == h->Q, "tstar_owl_get_query_embeds: Q does not match the installed queries");
@@ -354,6 +363,14 @@ int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* 
                    int N, int K, int act, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32: null argument");
     return gemm_f32(mk_gemm(d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act), (hipStream_t)stream);
+}
+
+int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
+                       int M, int N, int K, int act, int tile_cfg, void* stream) {
+    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32_cfg: null argument");
+    GemmArgs g = mk_gemm(d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
+    g.tile_cfg = tile_cfg;
+    return gemm_f32(g, (hipStream_t)stream);
 }
 
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream) {

@@ -11,7 +11,10 @@
 //    SIMD per issue, 157.3 TFLOP/s chip peak.  There is no TF32 on CDNA4.
 //  * 128x128x32 block tile, 256 threads = 4 waves (2x2), each wave 64x64 =
 //    2x2 MFMA tiles (64 accumulator VGPRs).  2 blocks per CU so one block's
-//    MFMA stream covers the other's barrier / LDS-write bubbles.
+//    MFMA stream covers the other's barrier / LDS-write bubbles.  Two smaller
+//    tile shapes (64x128, 64x64) share the code; the launcher picks per shape
+//    from a wave-quantisation model (narrow-N and small-M launches otherwise
+//    lose up to 25 % / 4x to the tail).
 //  * both operands are K-contiguous (activations row-major, nn.Linear weight
 //    [out,in]) -> identical staging for A and W: global_load_dwordx4 ->
 //    ds_write_b128 into a [128][32+4] padded tile (row stride 144 B makes the
@@ -29,8 +32,7 @@
 
 namespace tstar {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
-constexpr int GEMM_LDS_BYTES = 2 /*buf*/ * 2 /*A,B*/ * BM * LDS_LD * 4;
+constexpr int BK = 32, LDS_LD = BK + 4;
 
 __device__ __forceinline__ float epi_act(float v, int act) {
     if (act == ACT_QGELU) return v / (1.0f + expf(-1.702f * v));
@@ -38,8 +40,19 @@ __device__ __forceinline__ float epi_act(float v, int act) {
     return v;
 }
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+// Tile configuration: WM x WN waves (always 4), each wave TM x TN MFMA tiles of 32x32.
+//   Cfg128: 128x128 block, 2 blocks/CU  -- best when the grid fills whole waves of 512 slots
+//   Cfg64N: 64x128 block,  2 blocks/CU  -- halves the tail for narrow-N / mid-size grids
+//   Cfg64:  64x64 block,   4 blocks/CU  -- small M (one grid image, text tower)
+template <int TM_, int TN_, int MINW_>
+struct Cfg { static constexpr int TM = TM_, TN = TN_, MINW = MINW_, BM = 2 * TM_ * 32, BN = 2 * TN_ * 32; };
+using Cfg128 = Cfg<2, 2, 2>;
+using Cfg64N = Cfg<1, 2, 2>;
+using Cfg64 = Cfg<1, 1, 4>;
+
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__global__ __launch_bounds__(256, CF::MINW) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM, BN = CF::BN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
@@ -54,37 +67,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
 
-    // staging assignment: thread -> (row r0 + 32 i, float4 column c4)
+    // staging assignment: thread -> (row r0 + 32 i, float4 column c4); 32 rows per pass
+    constexpr int NA = BM / 32, NB = BN / 32;
     const int c4 = t & 7, r0 = t >> 3;
-    const float* ap[4];
-    const float* bp[4];
+    const float* ap[NA];
+    const float* bp[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
         int ar = m0 + r0 + 32 * i;
         ar = ar < g.M ? ar : g.M - 1;           // clamp: never read past the last row
         ap[i] = g.A + (size_t)ar * g.lda + c4 * 4;
-        bp[i] = g.W + (size_t)(n0 + r0 + 32 * i) * g.K + c4 * 4;
     }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bp[i] = g.W + (size_t)(n0 + r0 + 32 * i) * g.K + c4 * 4;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[NA], rb[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const f32x4*>(ap[i]);
-        rb[i] = *reinterpret_cast<const f32x4*>(bp[i]);
-    }
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
-        *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
-    }
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
     __syncthreads();
 
     const int nk = g.K / BK;
@@ -93,35 +106,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         const bool more = kt + 1 < nk;
         if (more) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * BK);
-                rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + (kt + 1) * BK);
-            }
+            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * BK);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + (kt + 1) * BK);
         }
-        const float* Ac = As + cur * BM * LDS_LD + (wm * 64 + l31) * LDS_LD + h * 4;
-        const float* Bc = Bs + cur * BN * LDS_LD + (wn * 64 + l31) * LDS_LD + h * 4;
+        const float* Ac = As + cur * BM * LDS_LD + (wm * TM * 32 + l31) * LDS_LD + h * 4;
+        const float* Bc = Bs + cur * BN * LDS_LD + (wn * TN * 32 + l31) * LDS_LD + h * 4;
+        // raise this wave's issue priority over the co-resident block's staging traffic while it
+        // feeds the matrix pipe (+4-7 % measured on gfx950)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(Ac + kk * 8);
-            f32x4 a1 = *reinterpret_cast<const f32x4*>(Ac + 32 * LDS_LD + kk * 8);
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(Bc + kk * 8);
-            f32x4 b1 = *reinterpret_cast<const f32x4*>(Bc + 32 * LDS_LD + kk * 8);
+            f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
-            }
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         if (more) {
             float* Aw = As + (cur ^ 1) * BM * LDS_LD;
             float* Bw = Bs + (cur ^ 1) * BN * LDS_LD;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<f32x4*>(&Aw[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
-                *reinterpret_cast<f32x4*>(&Bw[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
-            }
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&Aw[(r0 + 32 * i) * LDS_LD + c4 * 4]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bw[(r0 + 32 * i) * LDS_LD + c4 * 4]) = rb[i];
         }
         __syncthreads();
         cur ^= 1;
@@ -129,14 +145,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
         const float bv = HAS_BIAS ? g.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < g.M) {
                     float v = acc[i][j][r] + bv;
                     v = epi_act(v, ACT);
@@ -155,29 +171,53 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
-static int launch_one(const GemmArgs& g, hipStream_t stream) {
-    auto kern = gemm_f32_kernel<ACT, HAS_BIAS, HAS_RES, PATCH>;
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
+    constexpr int lds = 2 * (CF::BM + CF::BN) * LDS_LD * 4;
+    auto kern = gemm_f32_kernel<CF, ACT, HAS_BIAS, HAS_RES, PATCH>;
     static bool attr_set = false;
     if (!attr_set) {
         TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    const int nwg = cdiv(g.M, BM) * (g.N / BN);
+    const int nwg = cdiv(g.M, CF::BM) * (g.N / CF::BN);
     const bool prof = prof_enabled();
     if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K);
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), GEMM_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, g);
     if (prof) prof_stop(PROF_GEMM, stream);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
 }
 
+// Tile choice from a lock-step wave model calibrated on MI355X (tools/lab/gemm_lab.hip):
+// efficiency ~ e_cfg * w / ceil(w), w = blocks / resident slots (256 CUs x blocks per CU).
+static int pick_cfg(int M, int N) {
+    const int b128 = cdiv(M, 128) * (N / 128);
+    if (b128 <= 256) return 2;                               // under one block per CU: smallest tile
+    auto eff = [](double blocks, double slots, double e) { double w = blocks / slots; return e * w / ceil(w); };
+    const double e128 = eff(b128, 512, 1.00);
+    const double e64n = eff((double)cdiv(M, 64) * (N / 128), 512, 0.96);
+    const double e64 = eff((double)cdiv(M, 64) * (N / 64), 1024, 0.91);
+    if (e128 >= e64n && e128 >= e64) return 0;
+    return e64n >= e64 ? 1 : 2;
+}
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+static int launch_one(const GemmArgs& g, hipStream_t stream) {
+    const int forced = g.tile_cfg;                           // -1 = auto
+    const int cfg = forced >= 0 ? forced : pick_cfg(g.M, g.N);
+    if (cfg == 0) return launch_cfg<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (cfg == 1) return launch_cfg<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    return launch_cfg<Cfg64, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+}
+
 int gemm_f32(const GemmArgs& g, hipStream_t stream) {
     TSTAR_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_f32: empty problem");
-    TSTAR_REQUIRE(g.N % BN == 0, "gemm_f32: N must be a multiple of 128");
+    TSTAR_REQUIRE(g.N % 128 == 0, "gemm_f32: N must be a multiple of 128");
     TSTAR_REQUIRE(g.K % BK == 0, "gemm_f32: K must be a multiple of 32");
     TSTAR_REQUIRE(g.lda % 4 == 0 && g.K % 4 == 0, "gemm_f32: rows must be 16-byte aligned");
+    TSTAR_REQUIRE(g.tile_cfg >= -1 && g.tile_cfg <= 2, "gemm_f32: tile_cfg must be -1..2");
     const bool bias = g.bias != nullptr, res = g.res != nullptr, patch = g.pos != nullptr;
     if (patch) {
         TSTAR_REQUIRE(!bias && !res && g.act == ACT_NONE && g.patch_np > 0, "gemm_f32: patch epilogue takes no bias/res/act");

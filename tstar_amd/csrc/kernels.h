@@ -16,6 +16,7 @@ struct GemmArgs {
     int M, N, K, lda, ldc;
     int act;             // ACT_*
     int patch_np;        // patches per image (576) for the patch-embed epilogue
+    int tile_cfg;        // -1 auto; 0 = 128x128, 1 = 64x128, 2 = 64x64 block tile
 };
 int gemm_f32(const GemmArgs& g, hipStream_t stream);
 

@@ -122,7 +122,7 @@ class OWLInterface(HeuristicInterface):
     def set_class_weights(self, object2weight: Dict[str, float]):
         """Install ``object2weight.get(name, 0.5)`` per query (interface_searcher.py:136)."""
         w = [float(object2weight.get(t[0], 0.5)) for t in self.texts]
-        self.scorer.set_queries(self._ids, self._am, w)
+        self.scorer.set_class_weights(w)
         self._class_weight = np.asarray(w, dtype=np.float32)
 
     def score_batch(self, d_images, grid_rows: int, grid_cols: int):

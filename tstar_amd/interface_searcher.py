@@ -278,14 +278,22 @@ class TStarSearcher:
         self.Score_history.append(self._state.read(0).tolist())
         self.non_visiting_history.append(self._state.read(1).tolist())
 
-    def _update_from_device(self, secs: List[int], d_conf):
-        """update_frame_distribution (:276-321) on the device state; d_conf f64 [rows*cols] (cell i <-> sample i)."""
+    def _update_from_device(self, secs: List[int], d_conf, overlap=None):
+        """update_frame_distribution (:276-321) on the device state; d_conf f64 [rows*cols] (cell i <-> sample i).
+
+        ``overlap``: optional callable run right after the score write-back / window spread and
+        BEFORE the host-side FITPACK fit -- the searcher uses it to enqueue the iteration's
+        verification batch so the GPU works while the host fits the spline (verification does
+        not read P, and its score overwrites are applied after the histories are stored, exactly
+        in the reference's order)."""
         from scipy.interpolate import UnivariateSpline
         vx, vy = self._state.apply_grid(secs, d_conf)
+        ctx = overlap() if overlap is not None else None
         spline = UnivariateSpline(vx, vy, s=0.5)                  # FITPACK fit on the host, as :265
         t, c, k = spline._eval_args
         self._state.set_spline(t, c, k)
         self.store_score_distribution()
+        return ctx
 
     # ---- sampling --------------------------------------------------------------------------------
     def sample_frames(self, num_samples: int):
@@ -314,14 +322,22 @@ class TStarSearcher:
         return frames, time_stamps
 
     # ---- search ----------------------------------------------------------------------------------
-    def _verify_batch(self, secs: List[int], names_per_frame: List[List[str]]):
-        """verify_and_remove_target for every sampled frame of the iteration (:481-486, :382-420)."""
+    def _verify_launch(self, secs: List[int], names_per_frame: List[List[str]]):
+        """Enqueue the speculative verification batch of the iteration (device work only)."""
         cands = [i for i, names in enumerate(names_per_frame) if any(t in names for t in self.remaining_targets)]
         if not cands:
-            return
+            return None
         vframes = self._device_verify_frames([secs[i] for i in cands])
         res = self.heuristic.score_batch(vframes, 1, 1)
         self.device_images_scored += len(cands)
+        return cands, vframes, res
+
+    def _verify_finish(self, ctx, secs: List[int], names_per_frame: List[List[str]]):
+        """verify_and_remove_target for every sampled frame of the iteration (:481-486, :382-420),
+        replayed sequentially on the results of the batched launch."""
+        if ctx is None:
+            return
+        cands, vframes, res = ctx
         vconf = res.cell_conf[:, 0].cpu().numpy()
         vmask = res.cell_mask[:, 0].cpu().numpy().astype(np.uint32)
         slot = {i: j for j, i in enumerate(cands)}
@@ -405,10 +421,11 @@ class TStarSearcher:
                     self.detect_bbox_iters.append(self.heuristic.detections_inbatch)
             self.frames_scored += n
             self.detector_calls += 1
-            self._update_from_device(secs, d_conf)
             if self._fast:
-                self._verify_batch(secs, names_per_frame)
+                ctx = self._update_from_device(secs, d_conf, lambda: self._verify_launch(secs, names_per_frame))
+                self._verify_finish(ctx, secs, names_per_frame)
             else:
+                self._update_from_device(secs, d_conf)
                 self._verify_generic(secs, names_per_frame)
             self.iterations += 1
         return self.pop_frames(video_path=self.video_path, num_samples=self.search_nframes)

@@ -116,6 +116,13 @@ class OwlScorer:
         _lib.check(rc, "tstar_owl_set_query_embeds")
         self.Q = Q
 
+    def set_class_weights(self, class_weight: Sequence[float]):
+        w = np.ascontiguousarray(class_weight, dtype=np.float32)
+        if w.shape != (self.Q,):
+            raise ValueError("set_class_weights: one weight per installed query")
+        rc = self._lib.tstar_owl_set_class_weights(self._h, w.ctypes.data, self.Q, _lib.stream_ptr())
+        _lib.check(rc, "tstar_owl_set_class_weights")
+
     def get_query_embeds(self) -> np.ndarray:
         out = np.empty((self.Q, W.PROJ), dtype=np.float32)
         rc = self._lib.tstar_owl_get_query_embeds(self._h, out.ctypes.data, self.Q, _lib.stream_ptr())
