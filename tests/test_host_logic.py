@@ -1,0 +1,121 @@
+"""CPU: host-side logic, the C-ABI surface (symbols only; no compute without a GPU), sharding over
+gloo with world_size 2."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tstar_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "tstar_hip.h")).read()
+    declared = set(re.findall(r"\b(tstar_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.tstar_abi_version() == 1
+
+
+def test_blob_layout_matches_library():
+    from tstar_amd import _lib, weights as W
+    lib = _lib.load()
+    assert lib.tstar_owl_vision_blob_floats() == W.spec_size(W.vision_spec())
+    assert lib.tstar_owl_text_blob_floats() == W.spec_size(W.text_spec())
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from tstar_amd import _lib
+    from tstar_amd.owl import OwlScorer
+    from tstar_amd.interface_heuristic import OWLInterface
+    with pytest.raises(_lib.TStarHipError):
+        OwlScorer(np.zeros(4, np.float32))
+    with pytest.raises(ValueError, match="GPU only"):
+        OWLInterface(device="cpu", synthetic_seed=0)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tstar_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_tokenizer_standin_layout():
+    from tstar_amd.tokenizer import BOS, EOS, encode_queries, standin_word_id
+    ids, am = encode_queries([["couch"], ["a photo of tv"], [" "]])
+    assert ids.shape == (3, 16) and ids.dtype == np.int32
+    assert ids[0, 0] == BOS and ids[0, 2] == EOS and ids[0, 3] == 0 and am[0].sum() == 3
+    assert ids[1, 5] == EOS and am[1].sum() == 6
+    assert ids[2, 0] == BOS and ids[2, 1] == EOS and am[2].sum() == 2       # the blank background query
+    assert standin_word_id("Couch") == standin_word_id("couch") == ids[0, 1]
+
+
+def test_synthetic_weights_are_reproducible_and_shaped():
+    from tstar_amd import weights as W
+    a = W.synthetic_state_dict(3, "text")
+    b = W.synthetic_state_dict(3, "text")
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    blob = W.pack_blob(a, W.text_spec())
+    assert blob.size == W.spec_size(W.text_spec())
+    back = W.unpack_blob(blob, W.text_spec())
+    assert back["tok_emb"].shape == (W.VOCAB, W.T_D)
+    with pytest.raises(ValueError):
+        W.unpack_blob(blob[:-1], W.text_spec())
+    bb = W.compute_box_bias()
+    assert bb.shape == (576, 4) and abs(bb[0, 0] - (-3.1332)) < 1e-3 and abs(bb[-1, 0] - 9.2103) < 1e-3
+
+
+def test_synthetic_video_cpu_paths_agree():
+    from tstar_amd import video
+    idx = [0, 3, 17, 49]
+    a = video.synthetic_frames_numpy(idx, 50, seed=9)
+    b = video.synthetic_video(50, seed=9, device="cpu").frames[idx].numpy()
+    assert np.array_equal(a, b)
+    with pytest.raises(ValueError, match="Cannot open video file"):
+        video.open_video("/nonexistent.mp4", device="cpu")
+
+
+def test_shard_helpers():
+    from tstar_amd import sharding as Sh
+    assert Sh.shard_items(10, 4, 1) == [1, 5, 9]
+    rows = [[i, i + 1] for i in range(10)]
+    world = 4
+    gathered = []
+    for r in range(world):
+        gathered += [rows[i] for i in Sh.shard_items(10, world, r)]
+    assert Sh.interleave_by_item(gathered, 10, world) == rows
+    assert Sh.gather_keyframes([[1, 2]], 1) == [[1, 2]]
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from tstar_amd.sharding import run_sharded, item_seed
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+res = run_sharded(5, lambda i: [item_seed(100, i), i * i, 7], 2, int(sys.argv[3]))
+assert res == [[100 + i, i * i, 7] for i in range(5)], res
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_sharded_gather_world2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
