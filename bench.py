@@ -107,10 +107,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # one rank per GPU over RCCL; TSTAR_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a
+    # single-GPU box (ranks share the device, collectives go through host tensors)
+    backend = os.environ.get("TSTAR_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"
 
     from tstar_amd import _lib
     from tstar_amd.interface_heuristic import OWLInterface
@@ -145,7 +153,7 @@ def main():
     all_keys = gather_keyframes(keys, world)            # RCCL all-gather of the keyframe indices (N > 1)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt, float(frames), float(images)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, float(frames), float(images)], dtype=torch.float64, device=cdev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -169,6 +177,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
+                "collective_backend": (backend if world > 1 else None),
                 "workload": f"configs[1]: {args.nframes}-frame {FRAME_H}x{FRAME_W} synthetic RGB video resident in HBM, 1 question "
                             f"(targets {TARGETS}, cues {CUES}), OWL-ViT-B/32 fp32 (seeded synthetic weights), grid {g}x{g} = "
                             f"{g * g} frames/iter, search_nframes=8, threshold 0.6, budget 1000",

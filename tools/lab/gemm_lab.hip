@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void mfma_only(float* out, int iters) {
 }
 
 // WM x WN waves, each wave TM x TN tiles of 32x32; BM = WM*TM*32, BN = WN*TN*32
-template <int WM, int WN, int TM, int TN, int BK, int MINW, bool PRIO>
+template <int WM, int WN, int TM, int TN, int BK, int MINW, bool PRIO, int GM = 0>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_var(const float* __restrict__ A, const float* __restrict__ W,
                                                                float* __restrict__ C, const float* __restrict__ bias,
                                                                int M, int N, int K) {
@@ -37,7 +37,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_var(const float* __re
     float* As = smem; float* Bs = smem + 2 * BM * LD;
     const int nt = N / BN, mt = (M + BM - 1) / BM;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
-    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    int tm, tn;
+    if (GM == 0) { tm = tile / nt; tn = tile % nt; }
+    else {
+        const int per = GM * nt, grp = tile / per, loc = tile - grp * per;
+        const int rows = (mt - grp * GM) < GM ? (mt - grp * GM) : GM;      // last group may be short
+        tn = loc / rows; tm = grp * GM + loc % rows;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, h = lane >> 5;
     constexpr int F4R = BK / 4;                 // float4 per row
@@ -118,11 +125,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_var(const float* __re
     }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int MINW, bool PRIO>
+template <int WM, int WN, int TM, int TN, int BK, int MINW, bool PRIO, int GM = 0>
 float run(const char* name, const float* A, const float* W, float* C, const float* bias, int M, int N, int K, int iters) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BK + 4;
     const int lds = 2 * (BM + BN) * LD * 4;
-    auto k = gemm_var<WM, WN, TM, TN, BK, MINW, PRIO>;
+    auto k = gemm_var<WM, WN, TM, TN, BK, MINW, PRIO, GM>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int nwg = ((M + BM - 1) / BM) * (N / BN);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -158,14 +165,15 @@ int main() {
             printf("mfma_only %d blocks/CU: %.3f ms  %.1f TF\n", wpb, ms, (double)blocks * 4 * iters * 4 * 4096.0 / ms / 1e9);
         }
     }
-    struct Shape { int M, N, K; } shapes[] = {{9232, 768, 768}, {9232, 2304, 768}, {9232, 768, 3072}, {25388, 768, 768}, {25388, 2304, 768}, {25388, 768, 3072}, {36928, 768, 768}, {36928, 3072, 768}, {36928, 768, 3072}, {25344, 512, 768}, {577, 768, 768}, {577, 2304, 768}, {577, 768, 3072}, {2308, 768, 768}, {2308, 2304, 768}, {2308, 768, 3072}};
+    struct Shape { int M, N, K; } shapes[] = {{30016, 768, 768}, {30016, 2304, 768}, {30016, 3072, 768}, {30016, 768, 3072}, {25388, 768, 768}, {25388, 3072, 768}, {25388, 768, 3072}};
     for (auto s : shapes) {
-        run<2, 2, 2, 2, 32, 2, true>("128x128x32 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 1, 2, 32, 3, true>("64x128x32 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 2, 1, 32, 3, true>("128x64x32 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 1, 1, 32, 4, true>("64x64x32 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 1, 1, 64, 2, true>("64x64x64 4w prio", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<1, 4, 2, 1, 32, 3, true>("64x128x32 4w(1x4) prio", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 2, 2, 32, 2, true, 0>("128x128 rowmajor", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 2, 2, 32, 2, true, 4>("128x128 GM=4", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 2, 2, 32, 2, true, 8>("128x128 GM=8", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 2, 2, 32, 2, true, 16>("128x128 GM=16", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 1, 2, 32, 2, true, 0>("64x128 rowmajor", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 1, 2, 32, 2, true, 8>("64x128 GM=8", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 1, 2, 32, 2, true, 16>("64x128 GM=16", A, W, C, bias, s.M, s.N, s.K, 10);
         printf("\n");
     }
     return 0;

@@ -190,15 +190,18 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     return TSTAR_OK;
 }
 
-// Tile choice from a lock-step wave model calibrated on MI355X (tools/lab/gemm_lab.hip):
-// efficiency ~ e_cfg * w / ceil(w), w = blocks / resident slots (256 CUs x blocks per CU).
+// Tile choice from a wave model calibrated on MI355X (tools/lab/gemm_lab.hip): with
+// w = blocks / resident slots (256 CUs x blocks per CU), efficiency ~ e_cfg * w / (w + 0.5) for
+// w > 1 (half a wave of tail on average) and e_cfg * w below one wave.  e_cfg is the measured
+// steady-state rate of the tile shape relative to 128x128 (the narrower tiles re-stage the
+// operands more often; on wide-N problems 64x128 drops to 0.89).
 static int pick_cfg(int M, int N) {
     const int b128 = cdiv(M, 128) * (N / 128);
     if (b128 <= 256) return 2;                               // under one block per CU: smallest tile
-    auto eff = [](double blocks, double slots, double e) { double w = blocks / slots; return e * w / ceil(w); };
+    auto eff = [](double blocks, double slots, double e) { double w = blocks / slots; return e * (w <= 1.0 ? w : w / (w + 0.5)); };
     const double e128 = eff(b128, 512, 1.00);
-    const double e64n = eff((double)cdiv(M, 64) * (N / 128), 512, 0.96);
-    const double e64 = eff((double)cdiv(M, 64) * (N / 64), 1024, 0.91);
+    const double e64n = eff((double)cdiv(M, 64) * (N / 128), 512, N <= 1024 ? 0.96 : 0.89);
+    const double e64 = eff((double)cdiv(M, 64) * (N / 64), 1024, 0.90);
     if (e128 >= e64n && e128 >= e64) return 0;
     return e64n >= e64 ? 1 : 2;
 }
