@@ -150,7 +150,8 @@ int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* strea
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual); act: 0 none, 1 quick-gelu, 2 gelu(erf) */
 int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                    int M, int N, int K, int act, void* stream);
-/* same with the block tile forced: 0 = 128x128, 1 = 64x128, 2 = 64x64 (-1 = the launcher's choice) */
+/* same with the block tile forced: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = hybrid (128x128 + 64x128 tail);
+ * -1 = the launcher's choice */
 int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                        int M, int N, int K, int act, int tile_cfg, void* stream);
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream);

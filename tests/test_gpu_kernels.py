@@ -41,8 +41,8 @@ def test_gemm_bias_act(lib, M, N, K, act):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(577, 768, 3072), (130, 256, 64), (1154, 512, 768)])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(577, 768, 3072), (130, 256, 64), (1154, 512, 768), (25388, 768, 768)])
 def test_gemm_tile_configs(lib, cfg, M, N, K):
     """All three block-tile shapes compute the same product (the launcher picks per shape)."""
     g = torch.Generator().manual_seed(M + N + K)

@@ -125,6 +125,136 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_var(const float* __re
     }
 }
 
+
+// persistent variant: gridDim = slots; each block walks tiles; next tile's first K-slab is loaded
+// before the current tile's epilogue stores.
+template <int TM, int TN, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_persist(const float* __restrict__ A, const float* __restrict__ W,
+                                                          float* __restrict__ C, const float* __restrict__ bias,
+                                                          int M, int N, int K) {
+    constexpr int BK = 32, BM = 2 * TM * 32, BN = 2 * TN * 32, LD = BK + 4, NA = BM / 32, NB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem; float* Bs = smem + 2 * BM * LD;
+    const int nt = N / BN, mt = (M + BM - 1) / BM, ntiles = mt * nt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int c4 = t & 7, r0 = t >> 3;
+    // XCD-contiguous static schedule: block b (XCD b%8) takes tiles chunk_start + (b/8) + i*(G/8)
+    const int G = gridDim.x, xcd = blockIdx.x % 8, lb = blockIdx.x / 8, gpx = G / 8;
+    const int q = ntiles / 8, r = ntiles % 8;
+    const int cstart = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int clen = (xcd < r) ? q + 1 : q;
+    const float* ap[NA]; const float* bp[NB];
+    f32x4 ra[NA], rb[NB];
+    auto setup = [&](int tile, int& m0, int& n0) {
+        m0 = (tile / nt) * BM; n0 = (tile % nt) * BN;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { int ar = m0 + r0 + 32 * i; ar = ar < M ? ar : M - 1; ap[i] = A + (size_t)ar * K + c4 * 4; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bp[i] = W + (size_t)(n0 + r0 + 32 * i) * K + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i]);
+    };
+    int li = lb;
+    if (li >= clen) return;
+    int m0, n0;
+    setup(cstart + li, m0, n0);
+    const int nk = K / BK;
+    int cur = 0;
+    while (true) {
+        // stage slab 0 of this tile (registers already hold it)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[cur * BM * LD + (r0 + 32 * i) * LD + c4 * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[cur * BN * LD + (r0 + 32 * i) * LD + c4 * 4]) = rb[i];
+        __syncthreads();
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = 0.f;
+        const int cm0 = m0, cn0 = n0;
+        const int next_li = li + gpx;
+        const bool has_next = next_li < clen;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * BK);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp[i] + (kt + 1) * BK);
+            } else if (has_next) {
+                setup(cstart + next_li, m0, n0);          // prefetch next tile's slab 0 under the last MFMAs
+            }
+            const float* Ac = As + cur * BM * LD + (wm * TM * 32 + l31) * LD + h * 4;
+            const float* Bc = Bs + cur * BN * LD + (wn * TN * 32 + l31) * LD + h * 4;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LD + kk * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LD + kk * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[(cur ^ 1) * BM * LD + (r0 + 32 * i) * LD + c4 * 4]) = ra[i];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[(cur ^ 1) * BN * LD + (r0 + 32 * i) * LD + c4 * 4]) = rb[i];
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        // epilogue of the finished tile (next tile's loads are in flight)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = cn0 + wn * TN * 32 + j * 32 + l31;
+            const float bv = bias[col];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int row = cm0 + wm * TM * 32 + i * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                    if (row < M) C[(size_t)row * N + col] = acc[i][j][rr] + bv;
+                }
+        }
+        if (!has_next) break;
+        li = next_li;
+        cur ^= 1;        // the other buffer is free: every wave passed the barrier before the last compute
+        __syncthreads(); // all waves done reading the last slab before it is overwritten two tiles later
+    }
+}
+
+template <int TM, int TN, int MINW>
+float run_persist(const char* name, int bpc, const float* A, const float* W, float* C, const float* bias, int M, int N, int K, int iters) {
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, LD = 36;
+    const int lds = 2 * (BM + BN) * LD * 4;
+    auto k = gemm_persist<TM, TN, MINW>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int grid = 256 * bpc;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, A, W, C, bias, M, N, K);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, A, W, C, bias, M, N, K);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    printf("%-28s M=%6d N=%5d K=%5d lds=%6d grid=%5d  %8.3f ms %7.1f TF\n", name, M, N, K, lds, grid, ms, 2.0 * M * N * K / ms / 1e9);
+    return ms;
+}
+
 template <int WM, int WN, int TM, int TN, int BK, int MINW, bool PRIO, int GM = 0>
 float run(const char* name, const float* A, const float* W, float* C, const float* bias, int M, int N, int K, int iters) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LD = BK + 4;
@@ -165,15 +295,25 @@ int main() {
             printf("mfma_only %d blocks/CU: %.3f ms  %.1f TF\n", wpb, ms, (double)blocks * 4 * iters * 4 * 4096.0 / ms / 1e9);
         }
     }
-    struct Shape { int M, N, K; } shapes[] = {{30016, 768, 768}, {30016, 2304, 768}, {30016, 3072, 768}, {30016, 768, 3072}, {25388, 768, 768}, {25388, 3072, 768}, {25388, 768, 3072}};
+    // correctness check of the persistent kernel against the plain one
+    {
+        const int M = 3000, N = 768, K = 768;
+        float* C2; CK(hipMalloc(&C2, (size_t)M * N * 4));
+        run<2, 2, 2, 2, 32, 2, true, 0>("ref", A, W, C, bias, M, N, K, 1);
+        run_persist<2, 2, 2>("persist", 2, A, W, C2, bias, M, N, K, 1);
+        std::vector<float> h1((size_t)M * N), h2((size_t)M * N);
+        CK(hipMemcpy(h1.data(), C, h1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h2.data(), C2, h2.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0; for (size_t i = 0; i < h1.size(); ++i) md = fmax(md, fabs(h1[i] - h2[i]));
+        printf("persist vs ref max diff %g\n", md);
+    }
+    struct Shape { int M, N, K; } shapes[] = {{30016, 768, 768}, {30016, 2304, 768}, {30016, 3072, 768}, {30016, 768, 3072}, {25388, 768, 768}, {25388, 2304, 768}, {25388, 768, 3072}, {9232, 768, 768}, {9232, 3072, 768}};
     for (auto s : shapes) {
-        run<2, 2, 2, 2, 32, 2, true, 0>("128x128 rowmajor", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 2, 2, 32, 2, true, 4>("128x128 GM=4", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 2, 2, 32, 2, true, 8>("128x128 GM=8", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 2, 2, 32, 2, true, 16>("128x128 GM=16", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 1, 2, 32, 2, true, 0>("64x128 rowmajor", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 1, 2, 32, 2, true, 8>("64x128 GM=8", A, W, C, bias, s.M, s.N, s.K, 10);
-        run<2, 2, 1, 2, 32, 2, true, 16>("64x128 GM=16", A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 2, 2, 32, 2, true, 0>("128x128 plain", A, W, C, bias, s.M, s.N, s.K, 10);
+        run_persist<2, 2, 2>("128x128 persist 2/CU", 2, A, W, C, bias, s.M, s.N, s.K, 10);
+        run<2, 2, 1, 2, 32, 2, true, 0>("64x128 plain", A, W, C, bias, s.M, s.N, s.K, 10);
+        run_persist<1, 2, 2>("64x128 persist 2/CU", 2, A, W, C, bias, s.M, s.N, s.K, 10);
+        run_persist<1, 1, 4>("64x64 persist 4/CU", 4, A, W, C, bias, s.M, s.N, s.K, 10);
         printf("\n");
     }
     return 0;

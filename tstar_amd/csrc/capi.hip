@@ -121,7 +121,7 @@ static GemmArgs mk_gemm(const float* A, const float* W, float* C, const float* b
                         int K, int lda, int ldc, int act) {
     GemmArgs g{};
     g.A = A; g.W = W; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0; g.tile_cfg = -1;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0; g.tile_cfg = -1; g.m_split = 0;
     return g;
 }
 

@@ -50,17 +50,12 @@ using Cfg128 = Cfg<2, 2, 2>;
 using Cfg64N = Cfg<1, 2, 2>;
 using Cfg64 = Cfg<1, 1, 4>;
 
+// One output tile of shape CF at (m0, n0).  `smem` is the block's dynamic LDS.
 template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
-__global__ __launch_bounds__(256, CF::MINW) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int m0, const int n0, float* smem) {
     constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM, BN = CF::BN;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;       // [2][BN][LDS_LD]
-
-    const int nt = g.N / BN;
-    const int mt = (g.M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, mt * nt);
-    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -172,6 +167,33 @@ __global__ __launch_bounds__(256, CF::MINW) void gemm_f32_kernel(GemmArgs g) {
 }
 
 template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__global__ __launch_bounds__(256, CF::MINW) void gemm_f32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nt = g.N / CF::BN;
+    const int mt = (g.M + CF::BM - 1) / CF::BM;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    gemm_tile<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
+}
+
+// Hybrid launch: rows [0, m_split) in 128x128 tiles (whole waves of the 512 resident slots), the
+// remaining rows in 64x128 tiles.  Blocks are dispatched in index order, so the half-size tiles
+// arrive last and fill the tail that a pure 128x128 grid leaves on most CUs.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__global__ __launch_bounds__(256, 2) void gemm_f32_hybrid_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nt = g.N / 128;
+    const int n_big = (g.m_split / 128) * nt;
+    if ((int)blockIdx.x < n_big) {
+        const int tile = xcd_remap(blockIdx.x, n_big);
+        gemm_tile<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
+    } else {
+        const int n_small = gridDim.x - n_big;
+        const int tile = xcd_remap(blockIdx.x - n_big, n_small);
+        gemm_tile<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+    }
+}
+
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     constexpr int lds = 2 * (CF::BM + CF::BN) * LDS_LD * 4;
     auto kern = gemm_f32_kernel<CF, ACT, HAS_BIAS, HAS_RES, PATCH>;
@@ -190,26 +212,74 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     return TSTAR_OK;
 }
 
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
+    constexpr int lds = 2 * (128 + 128) * LDS_LD * 4;
+    auto kern = gemm_f32_hybrid_kernel<ACT, HAS_BIAS, HAS_RES, PATCH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int nt = g.N / 128;
+    const int nwg = (g.m_split / 128) * nt + cdiv(g.M - g.m_split, 64) * nt;
+    const bool prof = prof_enabled();
+    if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, g);
+    if (prof) prof_stop(PROF_GEMM, stream);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
 // Tile choice from a wave model calibrated on MI355X (tools/lab/gemm_lab.hip): with
 // w = blocks / resident slots (256 CUs x blocks per CU), efficiency ~ e_cfg * w / (w + 0.5) for
 // w > 1 (half a wave of tail on average) and e_cfg * w below one wave.  e_cfg is the measured
 // steady-state rate of the tile shape relative to 128x128 (the narrower tiles re-stage the
 // operands more often; on wide-N problems 64x128 drops to 0.89).
-static int pick_cfg(int M, int N) {
-    const int b128 = cdiv(M, 128) * (N / 128);
+// Returns 0/1/2 for a pure grid, or 3 for the hybrid launch with *m_split set (time in units of
+// one 128x128 tile on a fully resident CU pair).
+static int pick_cfg(int M, int N, int* m_split) {
+    *m_split = 0;
+    const int nt = N / 128;
+    const int b128 = cdiv(M, 128) * nt;
     if (b128 <= 256) return 2;                               // under one block per CU: smallest tile
-    auto eff = [](double blocks, double slots, double e) { double w = blocks / slots; return e * (w <= 1.0 ? w : w / (w + 0.5)); };
-    const double e128 = eff(b128, 512, 1.00);
-    const double e64n = eff((double)cdiv(M, 64) * (N / 128), 512, N <= 1024 ? 0.96 : 0.89);
-    const double e64 = eff((double)cdiv(M, 64) * (N / 64), 1024, 0.90);
-    if (e128 >= e64n && e128 >= e64) return 0;
-    return e64n >= e64 ? 1 : 2;
+    auto waves = [](double w) { return w <= 1.0 ? 1.0 : w + 0.5; };
+    const double e64n = N <= 1024 ? 0.96 : 0.92, e64 = 0.93;
+    const double t128 = waves(b128 / 512.0);
+    const double t64n = waves((double)cdiv(M, 64) * nt / 512.0) * 0.5 / e64n;
+    const double t64 = waves((double)cdiv(M, 64) * (N / 64) / 1024.0) * 0.5 / e64;   // 1024 quarter-size blocks = half a unit
+    // hybrid: as many whole 512-block waves of 128x128 tiles as fit, the rest as 64x128 tiles
+    double thyb = 1e30;
+    int split = 0;
+    const int full_rows = (512 / nt) > 0 ? ((b128 / 512) * 512 / nt) * 128 : 0;   // rows covered by whole waves
+    if (N <= 1024 && full_rows >= 128 && full_rows < M) {      // wide-N tails do not pay (measured)
+        split = full_rows;
+        const double rest = (double)cdiv(M - split, 64) * nt / 512.0;
+        thyb = (double)(split / 128) * nt / 512.0 + (rest <= 1.0 ? 1.0 : rest + 0.5) * 0.5 / e64n;
+    }
+    int best = 0;
+    double tb = t128;
+    if (t64n < tb) { tb = t64n; best = 1; }
+    if (t64 < tb) { tb = t64; best = 2; }
+    if (thyb < tb * 0.985) { best = 3; *m_split = split; }
+    return best;
 }
 
 template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_one(const GemmArgs& g, hipStream_t stream) {
     const int forced = g.tile_cfg;                           // -1 = auto
-    const int cfg = forced >= 0 ? forced : pick_cfg(g.M, g.N);
+    int m_split = 0;
+    int cfg = forced >= 0 ? forced : pick_cfg(g.M, g.N, &m_split);
+    if (forced == 3) {                                       // forced hybrid: half of the row tiles big
+        m_split = (cdiv(g.M, 128) / 2) * 128;
+        if (m_split == 0) cfg = 1;
+    }
+    if (cfg == 3) {
+        GemmArgs h = g;
+        h.m_split = m_split;
+        return launch_hybrid<ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
+    }
     if (cfg == 0) return launch_cfg<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
     if (cfg == 1) return launch_cfg<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
     return launch_cfg<Cfg64, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
@@ -220,7 +290,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t stream) {
     TSTAR_REQUIRE(g.N % 128 == 0, "gemm_f32: N must be a multiple of 128");
     TSTAR_REQUIRE(g.K % BK == 0, "gemm_f32: K must be a multiple of 32");
     TSTAR_REQUIRE(g.lda % 4 == 0 && g.K % 4 == 0, "gemm_f32: rows must be 16-byte aligned");
-    TSTAR_REQUIRE(g.tile_cfg >= -1 && g.tile_cfg <= 2, "gemm_f32: tile_cfg must be -1..2");
+    TSTAR_REQUIRE(g.tile_cfg >= -1 && g.tile_cfg <= 3, "gemm_f32: tile_cfg must be -1..3");
     const bool bias = g.bias != nullptr, res = g.res != nullptr, patch = g.pos != nullptr;
     if (patch) {
         TSTAR_REQUIRE(!bias && !res && g.act == ACT_NONE && g.patch_np > 0, "gemm_f32: patch epilogue takes no bias/res/act");

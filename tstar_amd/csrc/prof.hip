@@ -3,6 +3,7 @@
 // per-category (launches, total ms, total algorithmic flops).  Disabled by default (zero cost).
 #include "../../include/tstar_hip.h"
 #include "prof.h"
+#include <mutex>
 #include <vector>
 
 namespace tstar {
@@ -10,8 +11,11 @@ struct Pair { hipEvent_t a, b; double work; };
 struct Cat { std::vector<Pair> pending; std::vector<Pair> pool; long launches = 0; double ms = 0, work = 0; };
 static Cat g_cat[PROF_NCAT];
 static bool g_on = false;
+static std::mutex g_mu;      // searches may run on several host threads / streams
 
 bool prof_enabled() { return g_on; }
+
+static thread_local hipEvent_t t_last_b[PROF_NCAT] = {nullptr, nullptr};
 
 static void drain(Cat& c) {
     for (Pair& p : c.pending) {
@@ -25,6 +29,7 @@ static void drain(Cat& c) {
 }
 
 void prof_start(int cat, hipStream_t s, double work) {
+    std::lock_guard<std::mutex> lk(g_mu);
     Cat& c = g_cat[cat];
     if (c.pending.size() >= 16384) drain(c);
     Pair p;
@@ -33,23 +38,26 @@ void prof_start(int cat, hipStream_t s, double work) {
     p.work = work;
     (void)hipEventRecord(p.a, s);
     c.pending.push_back(p);
+    t_last_b[cat] = p.b;
 }
 
 void prof_stop(int cat, hipStream_t s) {
-    Cat& c = g_cat[cat];
-    if (!c.pending.empty()) (void)hipEventRecord(c.pending.back().b, s);
+    if (t_last_b[cat]) (void)hipEventRecord(t_last_b[cat], s);      // the stop event of THIS thread's last start
+    t_last_b[cat] = nullptr;
 }
 }  // namespace tstar
 
 using namespace tstar;
 extern "C" {
 int tstar_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
     for (int i = 0; i < PROF_NCAT; ++i) { drain(g_cat[i]); g_cat[i].launches = 0; g_cat[i].ms = 0; g_cat[i].work = 0; }
     return TSTAR_OK;
 }
 int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops) {
     TSTAR_REQUIRE(category >= 0 && category < PROF_NCAT && launches && total_ms && total_flops, "tstar_prof_read: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
     drain(g_cat[category]);
     *launches = g_cat[category].launches; *total_ms = g_cat[category].ms; *total_flops = g_cat[category].work;
     return TSTAR_OK;
