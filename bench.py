@@ -208,6 +208,17 @@ def main():
     _lib.check(lib.tstar_prof_read(1, C.byref(a_l), C.byref(a_ms), C.byref(a_fl)))
     _lib.check(lib.tstar_prof_enable(0))
     achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    # HBM-side traffic of the same kernel: rocprofv3 PMC passes of this command cannot run inside the
+    # timed process, so the per-launch figure measured with `tools/rocpd_traffic.py` is read from the
+    # committed summary (profiles/); None if it has not been collected.
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
+    if os.path.isfile(tp):
+        try:
+            tj = json.load(open(tp))
+            traffic, traffic_src = tj["bytes_per_launch_corrected"], "profiles/r01_pmc_gemm_traffic.json"
+        except Exception:
+            pass
 
     if rank == 0:
         out = {
@@ -228,7 +239,9 @@ def main():
             },
             "roofline": {
                 "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": achieved,
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_unit": "bytes per launch (L2 fabric side: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+                "traffic_source": traffic_src,
                 "launches": n_l.value, "avg_launch_ms": ms.value / max(n_l.value, 1),
                 "avg_launch_gflop": fl.value / max(n_l.value, 1) / 1e9,
                 "time_share_of_step": ms.value * 1e-3 / dt,
