@@ -332,3 +332,57 @@ def test_g9_end_to_end_vs_reference(golden_dir):
         assert s.detector_calls == ncalls
     print(f"G9: {same}/{len(ref_secs)} iterations on the reference trajectory; keyframes "
           f"{[float(t) for t in ts]} vs reference {g['time_stamps'].tolist()}")
+
+
+def test_config5_four_hour_video_bf16_weights():
+    """BASELINE config 5: 14400-frame video, search_nframes=32, grid 15x15 (225 frames/iter -> exactly 5
+    iterations under the 1000-frame cap), bf16-rounded weights.  Checked teacher-forced against the CPU
+    oracle running on the SAME rounded weights."""
+    from oracle import owl_ref, resize_ref as R, searcher_ref as S
+    from tstar_amd import weights as W
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_frames_numpy, synthetic_video
+    N, g, K = 14400, 15, 32
+    h = OWLInterface(synthetic_seed=0, max_batch=32, weights_dtype="bf16")
+    rec = _Recorder(h)
+    store = synthetic_video(N, seed=11)
+    s = TStarSearcher(store, h, ["couch"], ["tv", "chair"], search_nframes=K, image_grid_shape=(g, g),
+                      search_budget=1000, confidence_threshold=0.6, rng=np.random.RandomState(2025),
+                      keep_visual_history=False)
+    frames, ts = s.search()
+    assert s.iterations == 5 and len(ts) == K and frames.shape == (K, 360, 640, 3)
+    assert s.frames_scored == 5 * g * g + (s.detector_calls - 5)
+    # replay the device confidences through the oracle searcher: identical keyframes
+    names = [t[0] for t in h.texts]
+    calls = iter(rec.calls)
+    pending = {}
+
+    def score_fn(kind, secs, rows, cols):
+        if kind == "grid":
+            c = next(calls)
+            nm = [[names[q] for q in range(len(names)) if (int(m) >> q) & 1] for m in c["mask"][0]]
+            cands = [i for i, x in enumerate(nm[:len(secs)]) if "couch" in x]
+            if cands:
+                v = next(calls)
+                for j, i in enumerate(cands):
+                    pending[secs[i]] = (v["conf"][j, 0], v["mask"][j, 0])
+            return c["conf"][0].reshape(rows, cols), nm
+        conf, m = pending[secs[0]]
+        return np.array([[conf]]), [[names[q] for q in range(len(names)) if (int(m) >> q) & 1]]
+
+    ref = S.SearcherRef(N, 1.0, ["couch"], ["tv", "chair"], score_fn, np.random.RandomState(2025), search_nframes=K,
+                        image_grid_shape=(g, g), search_budget=1000, confidence_threshold=0.6)
+    assert ref.search() == [float(t) for t in ts]
+    # first grid image re-scored on the CPU with the same bf16-rounded weights
+    sd = W.round_weights_to_bf16(W.synthetic_state_dict(0))
+    wv = W.unpack_blob(W.pack_blob(sd, W.vision_spec()), W.vision_spec())
+    secs0 = ref.trace[0]["secs"]
+    grid_ref = R.frames_to_grid(list(synthetic_frames_numpy(secs0, N, seed=11)), g, g)
+    assert np.array_equal(rec.calls[0]["images"][0], grid_ref)
+    o = owl_ref.detect(R.owl_preprocess(grid_ref)[None], h.scorer.get_query_embeds(), wv, grid_ref.shape[0],
+                       grid_ref.shape[1], query_mask=np.ones(len(names), bool))
+    assert np.abs(o["dense"][0][0] - rec.calls[0]["scores"][0]).max() < 1e-3
+    # rounding really happened: a weight matrix holds only bf16-representable values
+    m = sd["owlvit.vision_model.encoder.layers.0.mlp.fc1.weight"]
+    assert np.all((m.view(np.uint32) & 0xFFFF) == 0)

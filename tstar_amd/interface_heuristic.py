@@ -53,12 +53,15 @@ class HeuristicInterface:
 
 class OWLInterface(HeuristicInterface):
     def __init__(self, model_name_or_path: str = "google/owlvit-base-patch32", device: str = "cuda",
-                 max_batch: int = 32, synthetic_seed: Optional[int] = None, state_dict: Optional[Dict] = None):
+                 max_batch: int = 32, synthetic_seed: Optional[int] = None, state_dict: Optional[Dict] = None,
+                 weights_dtype: str = "f32"):
         """``device`` must be a HIP device (default "cuda" as in the reference, :201).
 
         Weights: ``state_dict`` (HF names) if given; else a local safetensors checkpoint of
         ``model_name_or_path`` if one exists on disk; else, only when ``synthetic_seed`` is not None,
-        seeded synthetic weights (no checkpoint can be downloaded: there is no network)."""
+        seeded synthetic weights (no checkpoint can be downloaded: there is no network).
+        ``weights_dtype="bf16"`` rounds every weight matrix to bfloat16 (BASELINE config 5); the
+        arithmetic stays float32, so the result equals a CPU run on the same rounded weights."""
         import torch
         from .owl import OwlScorer
         if not str(device).startswith("cuda"):
@@ -80,6 +83,11 @@ class OWLInterface(HeuristicInterface):
                     "for seeded synthetic OWL-ViT-B/32 weights or state_dict=<HF state dict>")
         else:
             self.weights_source = "state_dict"
+        if weights_dtype not in ("f32", "bf16"):
+            raise ValueError("weights_dtype must be 'f32' or 'bf16'")
+        if weights_dtype == "bf16":
+            state_dict = W.round_weights_to_bf16(state_dict)
+        self.weights_dtype = weights_dtype
         self.model_name_or_path = model_name_or_path
         self.scorer = OwlScorer(W.pack_blob(state_dict, W.vision_spec()), W.pack_blob(state_dict, W.text_spec()),
                                 max_batch=max_batch)

@@ -224,6 +224,23 @@ def _hf_shape(hf: str) -> Tuple[int, ...]:
     return _HF_SHAPES[hf]
 
 
+def to_bf16_values(a: np.ndarray) -> np.ndarray:
+    """Round float32 values to the nearest bfloat16 (ties to even), returned as float32."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def round_weights_to_bf16(sd: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """BASELINE config 5 ("bf16 ViT weights"): every matrix / embedding table is rounded to bf16;
+    biases, LayerNorm parameters and the box_bias buffer stay float32."""
+    out = {}
+    for k, v in sd.items():
+        v = np.asarray(v, dtype=np.float32)
+        out[k] = to_bf16_values(v) if (v.ndim >= 2 and k != "box_bias") else v
+    return out
+
+
 def pack_blob(sd: Dict[str, np.ndarray], spec: Spec) -> np.ndarray:
     """Concatenate ``sd`` entries into the flat f32 blob the C ABI expects."""
     parts = []
