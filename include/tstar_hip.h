@@ -145,6 +145,13 @@ int tstar_searcher_set_scores(tstar_searcher* s, const int32_t* h_secs, const do
 /* copy a state array to the host: 0 score, 1 non_visiting, 2 P, 3 sampler p, 4 cdf.  Synchronises. */
 int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* stream);
 
+/* ------------------------------------------------------------------ downstream selection (8f)
+ * Replaces the score-based branch of extract_frames (LVHaystackBench/val_qa_results.py:90-110): the k
+ * highest-probability seconds of a per-second distribution d_P f64 [N] (device) inside
+ * [clip_start, clip_end), returned in ascending order (host int32 [k]); NaN -> 0, all-zero -> uniform;
+ * ties resolve to the lowest index.  Synchronises. */
+int tstar_topk_seconds(const double* d_P, int N, int clip_start, int clip_end, int k, int32_t* h_out, void* stream);
+
 /* ------------------------------------------------------------------ kernel-level diagnostics
  * (used by tests/ and bench.py to check and time individual kernels) */
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual); act: 0 none, 1 quick-gelu, 2 gelu(erf) */

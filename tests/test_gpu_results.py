@@ -1,0 +1,51 @@
+"""8f row 2: downstream top-k selection (GPU vs oracle) and the result wire format."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,k,clip", [(3600, 8, None), (3600, 8, (100.7, 460.2)), (14400, 32, None), (40, 8, (3, 11)),
+                                      (10, 10, None)])
+def test_topk_matches_oracle(n, k, clip):
+    from oracle import searcher_ref as S
+    from tstar_amd.results import topk_seconds
+    rs = np.random.RandomState(n + k)
+    p = rs.random_sample(n) ** 3
+    p[rs.random_sample(n) < 0.3] = p[0]           # ties
+    p[5] = np.nan
+    p /= np.nansum(p)
+    assert np.array_equal(topk_seconds(p, k, clip), S.topk_seconds(p, k, clip))
+
+
+def test_topk_degenerate_distributions():
+    from oracle import searcher_ref as S
+    from tstar_amd.results import topk_seconds
+    z = np.zeros(50)
+    assert np.array_equal(topk_seconds(z, 8), S.topk_seconds(z, 8)) and topk_seconds(z, 8).tolist() == list(range(8))
+    c = np.zeros(50)
+    c[40:] = 1.0                                   # clip region all zero -> uniform inside the clip
+    assert np.array_equal(topk_seconds(c, 4, (10, 30)), S.topk_seconds(c, 4, (10, 30)))
+
+
+def test_result_wire_format(tmp_path):
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.results import result_from_searcher, save_results, topk_seconds
+    from tstar_amd.video import synthetic_video
+    h = OWLInterface(synthetic_seed=0, max_batch=8)
+    s = TStarSearcher(synthetic_video(96, seed=3), h, ["couch"], ["tv"], search_nframes=4, image_grid_shape=(4, 4),
+                      search_budget=0.2, confidence_threshold=0.6, rng=np.random.RandomState(1), keep_visual_history=False)
+    s.search()
+    r = result_from_searcher(s)
+    assert set(r) == {"video_path", "grounding_objects", "keyframe_timestamps", "keyframe_distribution"}
+    assert r["grounding_objects"] == {"target_objects": ["couch"], "cue_objects": ["tv"]}
+    assert r["keyframe_timestamps"] == sorted(r["keyframe_timestamps"]) and len(r["keyframe_distribution"]) == 96
+    path = tmp_path / "out" / "results.json"
+    save_results([r], str(path))
+    back = json.load(open(path))
+    assert back[0]["keyframe_distribution"] == r["keyframe_distribution"]
+    sel = topk_seconds(back[0]["keyframe_distribution"], 8)
+    assert len(sel) == 8 and list(sel) == sorted(sel)

@@ -428,7 +428,9 @@ class TStarSearcher:
                 self._update_from_device(secs, d_conf)
                 self._verify_generic(secs, names_per_frame)
             self.iterations += 1
-        return self.pop_frames(video_path=self.video_path, num_samples=self.search_nframes)
+        frames, time_stamps = self.pop_frames(video_path=self.video_path, num_samples=self.search_nframes)
+        self.last_time_stamps = list(time_stamps)
+        return frames, time_stamps
 
     search_with_visualization = search
 
