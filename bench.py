@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--grid", type=int, default=16, help="grid side g (g*g frames per iteration)")
     ap.add_argument("--max-batch", type=int, default=64, help="detector images per forward chunk")
     ap.add_argument("--nframes", type=int, default=N_FRAMES)
+    ap.add_argument("--search-nframes", type=int, default=8)
+    ap.add_argument("--weights", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = BASELINE config 5 (bf16-rounded weights, exact-split bf16 MFMA GEMMs); with "
+                         "--nframes 14400 --grid 15 --search-nframes 32 this is configs[4]")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="independent searches in flight per GPU (host threads, one HIP stream + one scorer "
                          "workspace each); 2 fills kernel tails and gives ~+11 % throughput, but overlapping "
@@ -53,9 +57,9 @@ def parse():
     return ap.parse_args()
 
 
-def run_search(heuristic, store, g, seed):
+def run_search(heuristic, store, g, seed, k=8):
     from tstar_amd.interface_searcher import TStarSearcher
-    s = TStarSearcher(store, heuristic, list(TARGETS), list(CUES), search_nframes=8, image_grid_shape=(g, g),
+    s = TStarSearcher(store, heuristic, list(TARGETS), list(CUES), search_nframes=k, image_grid_shape=(g, g),
                       search_budget=1000, confidence_threshold=0.6, rng=np.random.RandomState(seed),
                       keep_visual_history=False)
     _, ts = s.search()
@@ -133,7 +137,8 @@ def main():
     import queue
     import threading
     conc = max(1, min(args.concurrency, args.steps))
-    heuristics = [OWLInterface(synthetic_seed=0, max_batch=args.max_batch, device=f"cuda:{local_rank}") for _ in range(conc)]
+    heuristics = [OWLInterface(synthetic_seed=0, max_batch=args.max_batch, device=f"cuda:{local_rank}",
+                               weights_dtype=args.weights) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
     store = synthetic_video(args.nframes, FRAME_H, FRAME_W, seed=0)
     g = args.grid
@@ -162,7 +167,7 @@ def main():
                         except queue.Empty:
                             break
                         t1 = time.perf_counter()
-                        s_, ts_ = run_search(heuristics[w], store, g, sd)
+                        s_, ts_ = run_search(heuristics[w], store, g, sd, args.search_nframes)
                         streams[w].synchronize()
                         out[i] = (s_, ts_, time.perf_counter() - t1)
             except Exception as e:                      # surface worker failures in the main thread
@@ -225,12 +230,13 @@ def main():
             "metric": "candidate frames scored/sec (whole node) + sec/video to 8 keyframes, 1h@1fps",
             "value": frames_all / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f32" if args.weights == "f32" else "f32 activations x bf16 weights (exact 3-term split on the bf16 MFMA pipe)"),
+            "data": "synthetic",
             "config": {
                 "collective_backend": (backend if world > 1 else None),
-                "workload": f"configs[1]: {args.nframes}-frame {FRAME_H}x{FRAME_W} synthetic RGB video resident in HBM, 1 question "
-                            f"(targets {TARGETS}, cues {CUES}), OWL-ViT-B/32 fp32 (seeded synthetic weights), grid {g}x{g} = "
-                            f"{g * g} frames/iter, search_nframes=8, threshold 0.6, budget 1000",
+                "workload": f"{'configs[1]' if args.weights == 'f32' and args.nframes == N_FRAMES else 'variant'}: {args.nframes}-frame {FRAME_H}x{FRAME_W} synthetic RGB video resident in HBM, 1 question "
+                            f"(targets {TARGETS}, cues {CUES}), OWL-ViT-B/32 {args.weights} weights (seeded synthetic), grid {g}x{g} = "
+                            f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
                 "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc,
                 "mean_search_latency_sec": latency,
                 "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,

@@ -55,9 +55,14 @@ typedef struct tstar_owl tstar_owl;
  * processed in chunks).  h_text_blob may be NULL (then only tstar_owl_set_query_embeds
  * can install queries).  h_norm_lut: 3*256 float32, the rescale+normalise value of every
  * (channel, u8) pair, computed by the host with the reference's arithmetic
- * (HF image_transforms.py rescale/normalize via image_processing_pil_owlvit.py). */
+ * (HF image_transforms.py rescale/normalize via image_processing_pil_owlvit.py).
+ * weights_bf16 != 0 (BASELINE config 5, "bf16 ViT weights"): every GEMM weight matrix is also kept
+ * as bfloat16 (round to nearest even; exact if the blob already holds bf16 values) and the GEMMs run
+ * on the bf16 matrix pipe with the float32 activations split exactly into three bf16 terms -- an
+ * f32-accumulated product of f32 activations and bf16 weights. */
 int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision,
-                     const float* h_text_blob, size_t n_text, const float* h_norm_lut, int max_batch);
+                     const float* h_text_blob, size_t n_text, const float* h_norm_lut, int max_batch,
+                     int weights_bf16);
 int tstar_owl_destroy(tstar_owl* h);
 
 /* Replaces the text half of processor(...)+model(...) that the reference recomputes on every
@@ -161,6 +166,9 @@ int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* 
  * -1 = the launcher's choice */
 int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                        int M, int N, int K, int act, int tile_cfg, void* stream);
+/* bf16-weight GEMM (diagnostic): W is rounded to bfloat16 on the device, A is split exactly; synchronises */
+int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
+                     int M, int N, int K, int act, int tile_cfg, void* stream);
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream);
 /* qkv [B*T, 3*heads*64] -> out [B*T, heads*64]; mode 0 full, 1 causal + key mask u8 [B,T] */
 int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode,

@@ -58,6 +58,45 @@ def test_gemm_tile_configs(lib, cfg, M, N, K):
     assert (dC.cpu() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K,act", [(577, 768, 3072, 0), (130, 256, 64, 1), (1154, 512, 768, 2), (25388, 768, 768, 0)])
+def test_gemm_bf16_weights_exact_split(lib, cfg, M, N, K, act):
+    """bf16-weight GEMM: f32 activations split exactly into 3 bf16 terms -> the f32-accumulated product
+    with the bf16-ROUNDED weights (compared against a float64 product of the same operands)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    A[::7] *= 1e-3                                             # wide dynamic range across rows
+    A[:, ::5] *= 37.0
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    Wr = W.to(torch.bfloat16).to(torch.float64)
+    ref = A.to(torch.float64) @ Wr.t() + b.to(torch.float64)
+    mag = A.abs().to(torch.float64) @ Wr.abs().t() + b.abs().to(torch.float64)
+    dA, dW, db = A.cuda(), W.cuda(), b.cuda()
+    dC = torch.full((M, N), float("nan"), device="cuda")
+    _check(lib.tstar_gemm_bf16w(dA.data_ptr(), dW.data_ptr(), dC.data_ptr(), db.data_ptr(), None, M, N, K, 0, cfg,
+                                torch.cuda.current_stream().cuda_stream))
+    out = dC.cpu().to(torch.float64)
+    assert torch.isfinite(out).all()
+    err = ((out - ref).abs() / mag).max().item()
+    assert err < 1e-6                                              # f32-roundoff class (grows slowly with K); bf16 activations would be ~4e-3
+    # the native f32 MFMA kernel on the same bf16-valued weights sits in the same error class
+    dWr = Wr.to(torch.float32).cuda()
+    dC32 = torch.empty((M, N), device="cuda")
+    _check(lib.tstar_gemm_f32(dA.data_ptr(), dWr.data_ptr(), dC32.data_ptr(), db.data_ptr(), None, M, N, K, 0,
+                              torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    err32 = ((dC32.cpu().to(torch.float64) - ref).abs() / mag).max().item()
+    assert err < 3 * err32 + 1e-7, (err, err32)
+    if act:
+        dC2 = torch.empty((M, N), device="cuda")
+        _check(lib.tstar_gemm_bf16w(dA.data_ptr(), dW.data_ptr(), dC2.data_ptr(), db.data_ptr(), None, M, N, K, act, cfg,
+                                    torch.cuda.current_stream().cuda_stream))
+        r32 = ref.to(torch.float32)
+        want = r32 * torch.sigmoid(1.702 * r32) if act == 1 else F.gelu(r32)
+        assert (dC2.cpu() - want).abs().max().item() < 3e-5 * max(1.0, want.abs().max().item())
+
+
 def test_gemm_asymmetric_identity(lib):
     """A = I against an asymmetric W: catches row/col swaps in the C/D layout."""
     N = K = 128

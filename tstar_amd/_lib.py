@@ -25,7 +25,7 @@ SIGNATURES = {
     "tstar_abi_version": (_i, []),
     "tstar_owl_vision_blob_floats": (_sz, []),
     "tstar_owl_text_blob_floats": (_sz, []),
-    "tstar_owl_create": (_i, [C.POINTER(_vp), _vp, _sz, _vp, _sz, _vp, _i]),
+    "tstar_owl_create": (_i, [C.POINTER(_vp), _vp, _sz, _vp, _sz, _vp, _i, _i]),
     "tstar_owl_destroy": (_i, [_vp]),
     "tstar_owl_set_queries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "tstar_owl_set_query_embeds": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
@@ -48,6 +48,7 @@ SIGNATURES = {
     "tstar_topk_seconds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "tstar_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tstar_gemm_f32_cfg": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tstar_gemm_bf16w": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tstar_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tstar_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tstar_prof_enable": (_i, [_i]),

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <map>
 #include <string.h>
+#include <unordered_map>
 #include <vector>
 
 namespace tstar {
@@ -28,6 +29,15 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int* __res
                                    int T, int D) {
     const int q = blockIdx.x;
     for (int d = threadIdx.x; d < D; d += blockDim.x) y[(size_t)q * D + d] = x[((size_t)q * T + eos[q]) * D + d];
+}
+// Wb[i] = bfloat16(W[i]), round to nearest even (exact when W already holds bf16 values)
+__global__ void f32_to_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ Wb, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) Wb[i] = (__bf16)W[i];
+}
+int convert_f32_to_bf16(const float* W, __bf16* Wb, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, s, W, Wb, n);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
 }
 // out[q,:] = in[q,:] / (||in[q,:]|| + eps); one wave per row, D = 512
 __global__ void l2norm_rows_kernel(const float* __restrict__ in, float* __restrict__ out, float eps) {
@@ -64,6 +74,14 @@ struct tstar_owl {
     int *d_ids = nullptr, *d_eos = nullptr;
     uint8_t* d_kmask = nullptr;
     std::map<int, ResampleTable> tabs;   // in_size -> table to 768
+    // bf16-weight mode (BASELINE config 5): bfloat16 copy of every GEMM weight matrix
+    bool bf16w = false;
+    std::unordered_map<const float*, __bf16*> wb;
+    const __bf16* bf16_of(const float* w) const {
+        if (!bf16w) return nullptr;
+        auto it = wb.find(w);
+        return it == wb.end() ? nullptr : it->second;
+    }
 };
 
 static size_t padded(size_t n) { return (n + 63) / 64 * 64; }
@@ -117,10 +135,10 @@ static int get_table(tstar_owl* h, int in_size, ResampleTable** out, hipStream_t
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-static GemmArgs mk_gemm(const float* A, const float* W, float* C, const float* bias, const float* res, int M, int N,
-                        int K, int lda, int ldc, int act) {
+static GemmArgs mk_gemm(const tstar_owl* h, const float* A, const float* W, float* C, const float* bias, const float* res,
+                        int M, int N, int K, int lda, int ldc, int act) {
     GemmArgs g{};
-    g.A = A; g.W = W; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
+    g.A = A; g.W = W; g.Wb = h ? h->bf16_of(W) : nullptr; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0; g.tile_cfg = -1; g.m_split = 0;
     return g;
 }
@@ -132,12 +150,12 @@ static int run_encoder(tstar_owl* h, const LayerW* layers, int nlayers, int B, i
     for (int l = 0; l < nlayers; ++l) {
         const LayerW& w = layers[l];
         RC(layernorm_f32(h->x, h->xn, w.ln1_w, w.ln1_b, M, D, s));
-        RC(gemm_f32(mk_gemm(h->xn, w.qkv_w, h->qkv, w.qkv_b, nullptr, M, 3 * D, D, D, 3 * D, ACT_NONE), s));
+        RC(gemm_f32(mk_gemm(h, h->xn, w.qkv_w, h->qkv, w.qkv_b, nullptr, M, 3 * D, D, D, 3 * D, ACT_NONE), s));
         RC(attention_f32(h->qkv, h->att, B, T, heads, mode, key_mask, s));
-        RC(gemm_f32(mk_gemm(h->att, w.out_w, h->x, w.out_b, h->x, M, D, D, D, D, ACT_NONE), s));
+        RC(gemm_f32(mk_gemm(h, h->att, w.out_w, h->x, w.out_b, h->x, M, D, D, D, D, ACT_NONE), s));
         RC(layernorm_f32(h->x, h->xn, w.ln2_w, w.ln2_b, M, D, s));
-        RC(gemm_f32(mk_gemm(h->xn, w.fc1_w, h->hid, w.fc1_b, nullptr, M, FF, D, D, FF, ACT_QGELU), s));
-        RC(gemm_f32(mk_gemm(h->hid, w.fc2_w, h->x, w.fc2_b, h->x, M, D, FF, FF, D, ACT_NONE), s));
+        RC(gemm_f32(mk_gemm(h, h->xn, w.fc1_w, h->hid, w.fc1_b, nullptr, M, FF, D, D, FF, ACT_QGELU), s));
+        RC(gemm_f32(mk_gemm(h, h->hid, w.fc2_w, h->x, w.fc2_b, h->x, M, D, FF, FF, D, ACT_NONE), s));
     }
     return TSTAR_OK;
 }
@@ -167,8 +185,35 @@ int tstar_abi_version(void) { return 1; }
 size_t tstar_owl_vision_blob_floats(void) { return vision_floats(); }
 size_t tstar_owl_text_blob_floats(void) { return text_floats(); }
 
+static int make_bf16_copies(tstar_owl* h) {
+    std::vector<std::pair<const float*, size_t>> mats;
+    mats.push_back({h->vw.patch_w, (size_t)V_D * V_PATCH_K});
+    auto layer = [&](const LayerW& l, int d, int ff) {
+        mats.push_back({l.qkv_w, (size_t)3 * d * d}); mats.push_back({l.out_w, (size_t)d * d});
+        mats.push_back({l.fc1_w, (size_t)ff * d}); mats.push_back({l.fc2_w, (size_t)d * ff});
+    };
+    for (int i = 0; i < V_LAYERS; ++i) layer(h->vw.layers[i], V_D, V_FF);
+    mats.push_back({h->vw.cls_w, (size_t)PROJ * V_D});
+    mats.push_back({h->vw.box0_w, (size_t)V_D * V_D});
+    mats.push_back({h->vw.box1_w, (size_t)V_D * V_D});
+    if (h->has_text) {
+        for (int i = 0; i < T_LAYERS; ++i) layer(h->tw.layers[i], T_D, T_FF);
+        mats.push_back({h->tw.text_proj, (size_t)PROJ * T_D});
+    }
+    for (auto& m : mats) {
+        __bf16* p = nullptr;
+        TSTAR_HIP_CHECK(hipMalloc(&p, m.second * sizeof(__bf16)));
+        h->wb[m.first] = p;
+        int rc = convert_f32_to_bf16(m.first, p, m.second, 0);
+        if (rc) return rc;
+    }
+    TSTAR_HIP_CHECK(hipDeviceSynchronize());
+    h->bf16w = true;
+    return TSTAR_OK;
+}
+
 int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision, const float* h_text_blob,
-                     size_t n_text, const float* h_norm_lut, int max_batch) {
+                     size_t n_text, const float* h_norm_lut, int max_batch, int weights_bf16) {
     TSTAR_REQUIRE(out && h_vision_blob && h_norm_lut, "tstar_owl_create: null argument");
     TSTAR_REQUIRE(max_batch >= 1 && max_batch <= 1024, "tstar_owl_create: max_batch must be in 1..1024");
     int ndev = 0;
@@ -205,6 +250,10 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
         tstar_owl_destroy(h);
         return TSTAR_ERR_HIP;
     }
+    if (weights_bf16) {
+        rc = make_bf16_copies(h);
+        if (rc) { tstar_owl_destroy(h); return rc; }
+    }
     *out = h;
     return TSTAR_OK;
 }
@@ -215,6 +264,7 @@ int tstar_owl_destroy(tstar_owl* h) {
                     h->qn, h->qweight, h->qmask, h->d_ids, h->d_eos, h->d_kmask};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : h->tabs) free_table(&kv.second);
+    for (auto& kv : h->wb) if (kv.second) (void)hipFree(kv.second);
     delete h;
     return TSTAR_OK;
 }
@@ -259,7 +309,7 @@ int tstar_owl_set_queries(tstar_owl* h, const int32_t* h_ids, const int32_t* h_a
     RC(layernorm_f32(h->x, h->xn, h->tw.final_ln_w, h->tw.final_ln_b, M, T_D, s));
     hipLaunchKernelGGL(gather_rows_kernel, dim3(Q), dim3(128), 0, s, h->xn, h->d_eos, h->att, T_LEN, T_D);
     TSTAR_HIP_CHECK(hipGetLastError());
-    RC(gemm_f32(mk_gemm(h->att, h->tw.text_proj, h->hid, nullptr, nullptr, Q, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
+    RC(gemm_f32(mk_gemm(h, h->att, h->tw.text_proj, h->hid, nullptr, nullptr, Q, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->hid, h->q_raw, 0.0f);
     TSTAR_HIP_CHECK(hipGetLastError());
     return finish_queries(h, qm.data(), h_w, Q, s);
@@ -306,7 +356,7 @@ int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, 
         const int Bc = (B - b0) < h->max_batch ? (B - b0) : h->max_batch;
         const int M = Bc * V_NTOK, MP = Bc * V_NP;
         RC(preprocess_chunk(h, d_images + (size_t)b0 * H * W * 3, Bc, H, W, nullptr, h->hid, s));
-        GemmArgs pg = mk_gemm(h->hid, h->vw.patch_w, h->x, nullptr, nullptr, MP, V_D, V_PATCH_K, V_PATCH_K, V_D, ACT_NONE);
+        GemmArgs pg = mk_gemm(h, h->hid, h->vw.patch_w, h->x, nullptr, nullptr, MP, V_D, V_PATCH_K, V_PATCH_K, V_D, ACT_NONE);
         pg.pos = h->vw.pos_emb; pg.patch_np = V_NP;
         RC(gemm_f32(pg, s));
         RC(write_cls_rows(h->x, h->vw.class_emb, h->vw.pos_emb, Bc, V_NTOK, V_D, s));
@@ -317,9 +367,9 @@ int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, 
         float* cls = h->att;      // [MP, 512]
         float* bh1 = h->qkv;      // [MP, 768]
         float* bh2 = h->hid;      // [MP, 768]
-        RC(gemm_f32(mk_gemm(feats, h->vw.cls_w, cls, h->vw.cls_b, nullptr, MP, PROJ, V_D, V_D, PROJ, ACT_NONE), s));
-        RC(gemm_f32(mk_gemm(feats, h->vw.box0_w, bh1, h->vw.box0_b, nullptr, MP, V_D, V_D, V_D, V_D, ACT_GELU), s));
-        RC(gemm_f32(mk_gemm(bh1, h->vw.box1_w, bh2, h->vw.box1_b, nullptr, MP, V_D, V_D, V_D, V_D, ACT_GELU), s));
+        RC(gemm_f32(mk_gemm(h, feats, h->vw.cls_w, cls, h->vw.cls_b, nullptr, MP, PROJ, V_D, V_D, PROJ, ACT_NONE), s));
+        RC(gemm_f32(mk_gemm(h, feats, h->vw.box0_w, bh1, h->vw.box0_b, nullptr, MP, V_D, V_D, V_D, V_D, ACT_GELU), s));
+        RC(gemm_f32(mk_gemm(h, bh1, h->vw.box1_w, bh2, h->vw.box1_b, nullptr, MP, V_D, V_D, V_D, V_D, ACT_GELU), s));
         DetectRowsArgs a{};
         a.feats = feats; a.cls = cls; a.boxh = bh2; a.qn = h->qn; a.qmask = h->qmask;
         a.shift_w = h->vw.shift_w; a.shift_b = h->vw.shift_b; a.scale_w = h->vw.scale_w; a.scale_b = h->vw.scale_b;
@@ -362,15 +412,34 @@ int tstar_frames_resize(const uint8_t* d_video, int N, int H, int W, const int32
 int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
                    int N, int K, int act, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32: null argument");
-    return gemm_f32(mk_gemm(d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act), (hipStream_t)stream);
+    return gemm_f32(mk_gemm(nullptr, d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act), (hipStream_t)stream);
 }
 
 int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                        int M, int N, int K, int act, int tile_cfg, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32_cfg: null argument");
-    GemmArgs g = mk_gemm(d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
+    GemmArgs g = mk_gemm(nullptr, d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
     g.tile_cfg = tile_cfg;
     return gemm_f32(g, (hipStream_t)stream);
+}
+
+int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
+                     int N, int K, int act, int tile_cfg, void* stream) {
+    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_bf16w: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    __bf16* wb = nullptr;
+    TSTAR_HIP_CHECK(hipMalloc(&wb, (size_t)N * K * sizeof(__bf16)));
+    int rc = convert_f32_to_bf16(d_W, wb, (size_t)N * K, s);
+    if (!rc) {
+        GemmArgs g = mk_gemm(nullptr, d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
+        g.Wb = wb;
+        g.tile_cfg = tile_cfg;
+        rc = gemm_f32(g, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(wb);
+    if (!rc && e != hipSuccess) { set_error(std::string("tstar_gemm_bf16w: ") + hipGetErrorString(e)); rc = TSTAR_ERR_HIP; }
+    return rc;
 }
 
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream) {

@@ -50,6 +50,166 @@ using Cfg128 = Cfg<2, 2, 2>;
 using Cfg64N = Cfg<1, 2, 2>;
 using Cfg64 = Cfg<1, 1, 4>;
 
+// Epilogue shared by the f32 and the bf16-weight tiles.  C/D layout of the 32x32 MFMA:
+// col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[CF::TM][CF::TN], const int m0, const int n0,
+                                              const int wm, const int wn, const int l31, const int h) {
+    constexpr int TM = CF::TM, TN = CF::TN;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        const float bv = HAS_BIAS ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    v = epi_act(v, ACT);
+                    size_t orow = row;
+                    if (PATCH) {
+                        // patch-embed rows (b, p) -> token rows (b, 1 + p), + position embedding
+                        const int b = row / g.patch_np, p = row - b * g.patch_np;
+                        orow = (size_t)b * (g.patch_np + 1) + 1 + p;
+                        v += g.pos[(size_t)(1 + p) * g.N + col];
+                    }
+                    if (HAS_RES) v += g.res[orow * g.ldc + col];
+                    g.C[orow * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16-WEIGHT tile (BASELINE config 5, "bf16 ViT weights"): W is stored as bfloat16 (half the
+// bytes), the float32 activations are split EXACTLY into three bfloat16 terms
+// a = a0 + a1 + a2 (8 + 8 + 8 significand bits, truncation split) while they are staged into LDS,
+// and C += a0*w + a1*w + a2*w runs on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate per
+// instruction, 3 instructions per K=16).  Every product is exact in f32, so the result is an
+// f32-accumulated dot product of the f32 activations with the bf16 weights -- the same quantity
+// the f32 tile computes from bf16-valued weights (measured error 1.2e-7 * sum|a w|, i.e.
+// f32-roundoff class) at 2.4-2.6x the speed.
+// LDS tiles are [rows][32 bf16] = 64 B per row with the 16-B chunk index XOR-swizzled by
+// (row >> 2) & 3, which makes both the ds_read_b128 fragment reads and the staging writes
+// conflict-free without padding (3 A-term tiles + 1 W tile, double buffered = 64 KB at 128x128).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int bfw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ void split4_bf16x3(const f32x4 v, u32x2 (&out)[3]) {
+    unsigned t[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float r = v[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned b = __float_as_uint(r) & 0xFFFF0000u;      // top 8 significand bits
+            t[k][e] = b;
+            r = r - __uint_as_float(b);                               // exact
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        out[k][0] = (t[k][0] >> 16) | t[k][1];
+        out[k][1] = (t[k][2] >> 16) | t[k][3];
+    }
+}
+
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0, const int n0, float* smem_f) {
+    constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM, BN = CF::BN;
+    constexpr int A_T = BM * 64, W_T = BN * 64, BUF = 3 * A_T + W_T;       // bytes
+    char* smem = reinterpret_cast<char*>(smem_f);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    constexpr int NA = BM / 32, NB = BN / 64;
+    const int c4 = t & 7, r0 = t >> 3;            // A: rows r0 + 32 i, float4 column c4
+    const int wc = t & 3, wr = t >> 2;            // W: rows wr + 64 i, 16-B chunk wc
+    const float* ap[NA];
+    const __bf16* bp[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int ar = m0 + r0 + 32 * i;
+        ar = ar < g.M ? ar : g.M - 1;
+        ap[i] = g.A + (size_t)ar * g.lda + c4 * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bp[i] = g.Wb + (size_t)(n0 + wr + 64 * i) * g.K + wc * 8;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NA];
+    u32x4 rb[NB];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(bp[i] + kt * BK);
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            u32x2 sp[3];
+            split4_bf16x3(ra[i], sp);
+            const int off = bfw_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(base + 3 * A_T + bfw_off(wr + 64 * i, wc)) = rb[i];
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int nk = g.K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        const char* base = smem + cur * BUF;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                       // two K = 16 steps per tile
+            bf16x8 fa[3][TM], fw[TN];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[k][i] = *reinterpret_cast<const bf16x8*>(base + k * A_T + bfw_off(wm * TM * 32 + i * 32 + l31, 2 * s + h));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fw[j] = *reinterpret_cast<const bf16x8*>(base + 3 * A_T + bfw_off(wn * TN * 32 + j * 32 + l31, 2 * s + h));
+#pragma unroll
+            for (int k = 2; k >= 0; --k)                    // smallest term first
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k][i], fw[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
+}
+
 // One output tile of shape CF at (m0, n0).  `smem` is the block's dynamic LDS.
 template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int m0, const int n0, float* smem) {
@@ -138,65 +298,43 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int m0, const
         cur ^= 1;
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 32 + j * 32 + l31;
-        const float bv = HAS_BIAS ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < g.M) {
-                    float v = acc[i][j][r] + bv;
-                    v = epi_act(v, ACT);
-                    size_t orow = row;
-                    if (PATCH) {
-                        // patch-embed rows (b, p) -> token rows (b, 1 + p), + position embedding
-                        const int b = row / g.patch_np, p = row - b * g.patch_np;
-                        orow = (size_t)b * (g.patch_np + 1) + 1 + p;
-                        v += g.pos[(size_t)(1 + p) * g.N + col];
-                    }
-                    if (HAS_RES) v += g.res[orow * g.ldc + col];
-                    g.C[orow * g.ldc + col] = v;
-                }
-            }
-        }
-    }
+    gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
 }
 
-template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <class CF, bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __global__ __launch_bounds__(256, CF::MINW) void gemm_f32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt = g.N / CF::BN;
     const int mt = (g.M + CF::BM - 1) / CF::BM;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
-    gemm_tile<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
+    if (BF16W) gemm_tile_bf16w<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
+    else gemm_tile<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
 }
 
 // Hybrid launch: rows [0, m_split) in 128x128 tiles (whole waves of the 512 resident slots), the
 // remaining rows in 64x128 tiles.  Blocks are dispatched in index order, so the half-size tiles
 // arrive last and fill the tail that a pure 128x128 grid leaves on most CUs.
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __global__ __launch_bounds__(256, 2) void gemm_f32_hybrid_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt = g.N / 128;
     const int n_big = (g.m_split / 128) * nt;
     if ((int)blockIdx.x < n_big) {
         const int tile = xcd_remap(blockIdx.x, n_big);
-        gemm_tile<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
+        if (BF16W) gemm_tile_bf16w<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
+        else gemm_tile<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
     } else {
         const int n_small = gridDim.x - n_big;
         const int tile = xcd_remap(blockIdx.x - n_big, n_small);
-        gemm_tile<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        if (BF16W) gemm_tile_bf16w<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        else gemm_tile<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
     }
 }
 
-template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <class CF, bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
-    constexpr int lds = 2 * (CF::BM + CF::BN) * LDS_LD * 4;
-    auto kern = gemm_f32_kernel<CF, ACT, HAS_BIAS, HAS_RES, PATCH>;
+    constexpr int lds = BF16W ? 2 * (3 * CF::BM + CF::BN) * 64 : 2 * (CF::BM + CF::BN) * LDS_LD * 4;
+    auto kern = gemm_f32_kernel<CF, BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>;
     static bool attr_set = false;
     if (!attr_set) {
         TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -212,10 +350,10 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     return TSTAR_OK;
 }
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
-    constexpr int lds = 2 * (128 + 128) * LDS_LD * 4;
-    auto kern = gemm_f32_hybrid_kernel<ACT, HAS_BIAS, HAS_RES, PATCH>;
+    constexpr int lds = BF16W ? 2 * (3 * 128 + 128) * 64 : 2 * (128 + 128) * LDS_LD * 4;
+    auto kern = gemm_f32_hybrid_kernel<BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>;
     static bool attr_set = false;
     if (!attr_set) {
         TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -266,8 +404,8 @@ static int pick_cfg(int M, int N, int* m_split) {
     return best;
 }
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
-static int launch_one(const GemmArgs& g, hipStream_t stream) {
+template <bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+static int launch_mode(const GemmArgs& g, hipStream_t stream) {
     const int forced = g.tile_cfg;                           // -1 = auto
     int m_split = 0;
     int cfg = forced >= 0 ? forced : pick_cfg(g.M, g.N, &m_split);
@@ -278,11 +416,17 @@ static int launch_one(const GemmArgs& g, hipStream_t stream) {
     if (cfg == 3) {
         GemmArgs h = g;
         h.m_split = m_split;
-        return launch_hybrid<ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
+        return launch_hybrid<BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
     }
-    if (cfg == 0) return launch_cfg<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
-    if (cfg == 1) return launch_cfg<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
-    return launch_cfg<Cfg64, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (cfg == 0) return launch_cfg<Cfg128, BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (cfg == 1) return launch_cfg<Cfg64N, BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    return launch_cfg<Cfg64, BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+}
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+static int launch_one(const GemmArgs& g, hipStream_t stream) {
+    if (g.Wb) return launch_mode<true, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    return launch_mode<false, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
 }
 
 int gemm_f32(const GemmArgs& g, hipStream_t stream) {

@@ -60,8 +60,10 @@ class OWLInterface(HeuristicInterface):
         Weights: ``state_dict`` (HF names) if given; else a local safetensors checkpoint of
         ``model_name_or_path`` if one exists on disk; else, only when ``synthetic_seed`` is not None,
         seeded synthetic weights (no checkpoint can be downloaded: there is no network).
-        ``weights_dtype="bf16"`` rounds every weight matrix to bfloat16 (BASELINE config 5); the
-        arithmetic stays float32, so the result equals a CPU run on the same rounded weights."""
+        ``weights_dtype="bf16"`` rounds every weight matrix to bfloat16 (BASELINE config 5) and runs the
+        GEMMs on the bf16 matrix pipe with the float32 activations split exactly into three bf16 terms:
+        products are exact and accumulate in float32, so the result equals a CPU float32 run on the
+        same rounded weights up to summation order."""
         import torch
         from .owl import OwlScorer
         if not str(device).startswith("cuda"):
@@ -90,7 +92,7 @@ class OWLInterface(HeuristicInterface):
         self.weights_dtype = weights_dtype
         self.model_name_or_path = model_name_or_path
         self.scorer = OwlScorer(W.pack_blob(state_dict, W.vision_spec()), W.pack_blob(state_dict, W.text_spec()),
-                                max_batch=max_batch)
+                                max_batch=max_batch, weights_bf16=(weights_dtype == "bf16"))
         self.device = device
         self.texts = ["couch", "table", "woman"]      # as the reference leaves it before reparameterisation (:203)
         self.detections_inbatch: List[Detections] = []

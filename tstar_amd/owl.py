@@ -51,7 +51,8 @@ class ScoreResult:
 class OwlScorer:
     """One OWL-ViT-B/32 scorer resident on the current HIP device."""
 
-    def __init__(self, vision_blob: np.ndarray, text_blob: Optional[np.ndarray] = None, max_batch: int = 32):
+    def __init__(self, vision_blob: np.ndarray, text_blob: Optional[np.ndarray] = None, max_batch: int = 32,
+                 weights_bf16: bool = False):
         import torch
         if not torch.cuda.is_available():
             raise _lib.TStarHipError("OwlScorer needs a HIP device (torch.cuda.is_available() is False); "
@@ -66,7 +67,7 @@ class OwlScorer:
         rc = self._lib.tstar_owl_create(
             C.byref(h), vision_blob.ctypes.data, vision_blob.size,
             None if text_blob is None else text_blob.ctypes.data, 0 if text_blob is None else text_blob.size,
-            lut.ctypes.data, int(max_batch))
+            lut.ctypes.data, int(max_batch), int(bool(weights_bf16)))
         _lib.check(rc, "tstar_owl_create")
         self._h = h
         self.max_batch = int(max_batch)
