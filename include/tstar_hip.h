@@ -157,6 +157,13 @@ int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* strea
  * ties resolve to the lowest index.  Synchronises. */
 int tstar_topk_seconds(const double* d_P, int N, int clip_start, int clip_end, int k, int32_t* h_out, void* stream);
 
+/* Replaces pairwise_ssim / ssim_torch (LVHaystackBench/val_tstar_results.py:48-95): SSIM of every
+ * (ground-truth, predicted) keyframe pair, frames u8 [G,H,W,3] / [P,H,W,3] on the device, 11x11 Gaussian
+ * window (host float32 [121], sigma 1.5) -> d_out f64 [G,P].  Keeps the reference's HWC-as-CHW layout
+ * quirk (the window slides over the (W, colour) plane of each row).  Synchronises. */
+int tstar_ssim_pairwise(const uint8_t* d_gt, int G, const uint8_t* d_pred, int P, int H, int W,
+                        const float* h_window, double* d_out, void* stream);
+
 /* ------------------------------------------------------------------ kernel-level diagnostics
  * (used by tests/ and bench.py to check and time individual kernels) */
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual); act: 0 none, 1 quick-gelu, 2 gelu(erf) */

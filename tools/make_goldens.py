@@ -318,9 +318,36 @@ def g7_g8_g9(TStarSearcher):
     print("g9 done: calls", len(conf_log), "ts", ts)
 
 
+def g10_metrics():
+    """Search-quality metrics of LVHaystackBench/val_tstar_results.py (imported unmodified)."""
+    sk = types.ModuleType("skimage")
+    skm = types.ModuleType("skimage.metrics")
+    skm.structural_similarity = lambda *a, **k: None            # imported by the reference, never called
+    sk.metrics = skm
+    sys.modules.update({"skimage": sk, "skimage.metrics": skm})
+    sys.path.insert(0, os.path.join(REF, "LVHaystackBench"))
+    import val_tstar_results as V
+    gt_idx, pred_idx = [3, 10, 17], [3, 11, 40, 41]
+    frames_gt = list(synthetic_frames_numpy(gt_idx, 64, 72, 128, seed=8))
+    frames_pr = list(synthetic_frames_numpy(pred_idx, 64, 72, 128, seed=8))
+    m = V.pairwise_ssim(frames_gt, frames_pr)
+    scores = V.calculate_ssim_scores([frames_gt], [frames_pr])
+    lg = [np.array([3.0, 10.0, 17.0, 100.0]), np.array([]), np.array([5.0, 50.0])]
+    lp = [np.array([2.0, 16.5, 60.0]), np.array([1.0]), np.array([44.0, 45.0, 46.0, 200.0])]
+    prf = V.calculate_prf(lg, lp, threshold=5)
+    annd = V.calculate_annd(lg, lp)
+    np.savez_compressed(os.path.join(OUT, "g10_metrics.npz"), gt_idx=np.array(gt_idx), pred_idx=np.array(pred_idx),
+                        video=np.array([64, 72, 128, 8]), ssim=m, ssim_scores=np.array(scores, dtype=np.float64),
+                        prf=np.array(prf, dtype=np.float64), annd=np.array(annd, dtype=np.float64))
+    print("g10 done", m.round(4).tolist(), prf)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
+    if "--only-g10" in sys.argv:
+        g10_metrics()
+        return
     import matplotlib
     matplotlib.use("Agg")
     from TStar.interface_searcher import TStarSearcher
@@ -331,6 +358,7 @@ def main():
             g1_searcher(TStarSearcher)
             g2_to_g6(TStarSearcher)
             g7_g8_g9(TStarSearcher)
+            g10_metrics()
         finally:
             os.chdir(cwd)
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "tstar_searcher_set_scores": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tstar_searcher_read": (_i, [_vp, _i, _vp, _vp]),
     "tstar_topk_seconds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "tstar_ssim_pairwise": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tstar_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tstar_gemm_f32_cfg": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tstar_gemm_bf16w": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
