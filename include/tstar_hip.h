@@ -107,15 +107,21 @@ int tstar_owl_debug_preprocess(tstar_owl* h, const uint8_t* d_images, int B, int
                                void* stream);
 
 /* ------------------------------------------------------------------ ingest (S1-S3, S8) */
-/* Replaces read_frame_batch + cv2.resize(800x380) + create_image_grid's cv2.resize(200x95) +
+/* The resident decoded video d_video is u8 [N,H,W,3] RGB (nv12 = 0) or NV12 u8 [N, H*3/2, W] (nv12 = 1:
+ * luma plane + interleaved half-resolution UV plane, converted on the fly, BT.601 limited range, nearest
+ * chroma -- half the bytes per frame).
+ * Replaces read_frame_batch + cv2.resize(800x380) + create_image_grid's cv2.resize(200x95) +
  * hstack/vstack (interface_searcher.py:157-169, 362, 186-188): gathers rows*cols frames by index
- * from a resident decoded video u8 [N,H,W,3] and writes the grid image u8 [rows*95, cols*200, 3]. */
+ * and writes the grid image u8 [rows*95, cols*200, 3]. */
 int tstar_frames_to_grid(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx,
-                         int grid_rows, int grid_cols, uint8_t* d_grid, void* stream);
+                         int grid_rows, int grid_cols, uint8_t* d_grid, int nv12, void* stream);
 /* Replaces read_frame_batch + cv2.resize (interface_searcher.py:402-403; any target size):
  * out u8 [n,out_h,out_w,3]. */
 int tstar_frames_resize(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n,
-                        int out_w, int out_h, uint8_t* d_out, void* stream);
+                        int out_w, int out_h, uint8_t* d_out, int nv12, void* stream);
+/* Native-resolution RGB u8 [n,H,W,3] of NV12 frames (the keyframes pop_frames hands back, :379-380). */
+int tstar_nv12_to_rgb(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n,
+                      uint8_t* d_out, void* stream);
 
 /* ------------------------------------------------------------------ searcher state (S-rows)
  * Device-resident float64 state of one TStarSearcher (interface_searcher.py:73-75):

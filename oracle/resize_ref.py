@@ -155,3 +155,20 @@ def frames_to_grid(frames, rows: int, cols: int) -> np.ndarray:
         raise ValueError("Frame count does not match grid dimensions")
     small = [cv_bilinear_resize(cv_bilinear_resize(f, 800, 380), 200, 95) for f in frames]
     return np.vstack([np.hstack(small[i * cols:(i + 1) * cols]) for i in range(rows)])
+
+
+def nv12_to_rgb(frame: np.ndarray) -> np.ndarray:
+    """NV12 uint8 [H*3/2, W] -> RGB uint8 [H,W,3]: BT.601 limited-range integer matrix, nearest chroma.
+    PARITY UNPINNED (the reference receives RGB from decord/swscale and never sees NV12): this is the
+    build's own definition of the NV12 ingest variant, mirrored by SrcNV12 in
+    tstar_amd/csrc/preprocess.hip."""
+    H = frame.shape[0] * 2 // 3
+    W = frame.shape[1]
+    y = frame[:H].astype(np.int64) - 16
+    uv = frame[H:].reshape(H // 2, W // 2, 2).astype(np.int64) - 128
+    d = np.repeat(np.repeat(uv[..., 0], 2, 0), 2, 1)
+    e = np.repeat(np.repeat(uv[..., 1], 2, 0), 2, 1)
+    r = (298 * y + 409 * e + 128) >> 8
+    g = (298 * y - 100 * d - 208 * e + 128) >> 8
+    b = (298 * y + 516 * d + 128) >> 8
+    return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)

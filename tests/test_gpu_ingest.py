@@ -1,0 +1,94 @@
+"""Ingest kernels: gather + cv-style bilinear + grid tiling (RGB and NV12 stores) vs the oracle, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from tstar_amd import _lib
+    return _lib, _lib.load()
+
+
+@pytest.mark.parametrize("g", [1, 4, 15])
+def test_frames_to_grid_rgb(g):
+    from oracle import resize_ref as R
+    from tstar_amd.video import synthetic_frames_numpy, synthetic_video
+    L, lib = _lib()
+    N = 300
+    st = synthetic_video(N, seed=4)
+    secs = list(np.random.RandomState(g).choice(N, g * g, replace=False))
+    idx = torch.tensor(secs, dtype=torch.int32, device="cuda")
+    grid = torch.empty((95 * g, 200 * g, 3), dtype=torch.uint8, device="cuda")
+    L.check(lib.tstar_frames_to_grid(st.frames.data_ptr(), N, 360, 640, idx.data_ptr(), g, g, grid.data_ptr(), 0, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(grid.cpu().numpy(), R.frames_to_grid(list(synthetic_frames_numpy(secs, N, seed=4)), g, g))
+
+
+@pytest.mark.parametrize("ow,oh", [(600, 285), (800, 380), (640, 360), (37, 11)])
+def test_frames_resize_rgb(ow, oh):
+    from oracle import resize_ref as R
+    from tstar_amd.video import synthetic_frames_numpy, synthetic_video
+    L, lib = _lib()
+    N = 40
+    st = synthetic_video(N, seed=6)
+    secs = [5, 0, 39]
+    idx = torch.tensor(secs, dtype=torch.int32, device="cuda")
+    out = torch.empty((3, oh, ow, 3), dtype=torch.uint8, device="cuda")
+    L.check(lib.tstar_frames_resize(st.frames.data_ptr(), N, 360, 640, idx.data_ptr(), 3, ow, oh, out.data_ptr(), 0, None))
+    torch.cuda.synchronize()
+    fr = synthetic_frames_numpy(secs, N, seed=6)
+    for k in range(3):
+        assert np.array_equal(out[k].cpu().numpy(), R.cv_bilinear_resize(fr[k], ow, oh))
+
+
+def test_nv12_store_matches_rgb_of_converted_frames():
+    """NV12 ingest = the RGB ingest applied to the converted frames (conversion fused into the taps)."""
+    from oracle import resize_ref as R
+    from tstar_amd.video import synthetic_nv12_numpy, synthetic_video_nv12
+    L, lib = _lib()
+    N, g = 64, 4
+    st = synthetic_video_nv12(N, seed=9)
+    assert st.fmt == "nv12" and st.frames.shape == (N, 540, 640) and st.shape == (N, 360, 640, 3)
+    secs = list(range(0, N, 4))
+    nv = synthetic_nv12_numpy(secs, N, seed=9)
+    assert np.array_equal(st.frames[secs].cpu().numpy(), nv)
+    rgb = [R.nv12_to_rgb(f) for f in nv]
+    assert np.array_equal(st.host_frames(secs[:3]), np.stack(rgb[:3]))
+    idx = torch.tensor(secs, dtype=torch.int32, device="cuda")
+    grid = torch.empty((95 * g, 200 * g, 3), dtype=torch.uint8, device="cuda")
+    L.check(lib.tstar_frames_to_grid(st.frames.data_ptr(), N, 360, 640, idx.data_ptr(), g, g, grid.data_ptr(), 1, None))
+    out = torch.empty((2, 285, 600, 3), dtype=torch.uint8, device="cuda")
+    L.check(lib.tstar_frames_resize(st.frames.data_ptr(), N, 360, 640, idx.data_ptr(), 2, 600, 285, out.data_ptr(), 1, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(grid.cpu().numpy(), R.frames_to_grid(rgb, g, g))
+    assert np.array_equal(out[1].cpu().numpy(), R.cv_bilinear_resize(rgb[1], 600, 285))
+
+
+def test_search_on_nv12_store_equals_search_on_converted_rgb_store():
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import FrameStore, load_video_frames, synthetic_video_nv12
+    N = 96
+    nv = synthetic_video_nv12(N, seed=2)
+    rgb = FrameStore(torch.from_numpy(nv.host_frames(range(N))).cuda(), 1.0)
+    h = OWLInterface(synthetic_seed=0, max_batch=8)
+    res = []
+    for st in (nv, rgb):
+        s = TStarSearcher(st, h, ["couch"], ["tv"], search_nframes=4, image_grid_shape=(4, 4), search_budget=0.4,
+                          confidence_threshold=0.6, rng=np.random.RandomState(3), keep_visual_history=False)
+        fr, ts = s.search()
+        res.append((fr, ts, s.score_distribution))
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][2], res[1][2])
+    u = load_video_frames(nv, 8)                      # the grounder's uniform loader (utilites.py:40-81)
+    assert u.shape == (8, 360, 640, 3) and np.array_equal(u[1], nv.host_frames([12])[0])
+
+
+def test_ingest_rejects_bad_arguments():
+    L, lib = _lib()
+    d = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    i = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.tstar_frames_to_grid(d.data_ptr(), 1, 1, 4, i.data_ptr(), 1, 1, d.data_ptr(), 0, None) == 1
+    assert lib.tstar_frames_resize(d.data_ptr(), 1, 3, 4, i.data_ptr(), 1, 2, 2, d.data_ptr(), 1, None) == 1   # odd H, NV12
+    assert lib.tstar_frames_to_grid(None, 1, 2, 2, i.data_ptr(), 1, 1, d.data_ptr(), 0, None) == 1

@@ -33,8 +33,9 @@ SIGNATURES = {
     "tstar_owl_get_query_embeds": (_i, [_vp, _vp, _i, _vp]),
     "tstar_owl_score": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tstar_owl_debug_preprocess": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "tstar_frames_to_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
-    "tstar_frames_resize": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "tstar_frames_to_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "tstar_frames_resize": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "tstar_nv12_to_rgb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "tstar_searcher_create": (_i, [C.POINTER(_vp), _i, C.c_double, C.c_double]),
     "tstar_searcher_destroy": (_i, [_vp]),
     "tstar_searcher_apply_grid": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -396,17 +396,26 @@ int tstar_owl_debug_preprocess(tstar_owl* h, const uint8_t* d_images, int B, int
 }
 
 int tstar_frames_to_grid(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int grid_rows,
-                         int grid_cols, uint8_t* d_grid, void* stream) {
+                         int grid_cols, uint8_t* d_grid, int nv12, void* stream) {
     TSTAR_REQUIRE(d_video && d_frame_idx && d_grid, "tstar_frames_to_grid: null argument");
     TSTAR_REQUIRE(N >= 1 && H >= 2 && W >= 2, "tstar_frames_to_grid: bad video shape");
-    return frames_to_grid_u8(d_video, H, W, d_frame_idx, grid_rows, grid_cols, 200, 95, d_grid, (hipStream_t)stream);
+    TSTAR_REQUIRE(!nv12 || (H % 2 == 0 && W % 2 == 0), "tstar_frames_to_grid: NV12 needs even dimensions");
+    return frames_to_grid_u8(d_video, H, W, d_frame_idx, grid_rows, grid_cols, 200, 95, d_grid, nv12, (hipStream_t)stream);
 }
 
 int tstar_frames_resize(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n, int out_w,
-                        int out_h, uint8_t* d_out, void* stream) {
+                        int out_h, uint8_t* d_out, int nv12, void* stream) {
     TSTAR_REQUIRE(d_video && d_frame_idx && d_out, "tstar_frames_resize: null argument");
     TSTAR_REQUIRE(N >= 1 && H >= 2 && W >= 2, "tstar_frames_resize: bad video shape");
-    return bilinear_gather_u8(d_video, H, W, d_frame_idx, n, out_w, out_h, d_out, (hipStream_t)stream);
+    TSTAR_REQUIRE(!nv12 || (H % 2 == 0 && W % 2 == 0), "tstar_frames_resize: NV12 needs even dimensions");
+    return bilinear_gather_u8(d_video, H, W, d_frame_idx, n, out_w, out_h, d_out, nv12, (hipStream_t)stream);
+}
+
+int tstar_nv12_to_rgb(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n, uint8_t* d_out,
+                      void* stream) {
+    TSTAR_REQUIRE(d_video && d_frame_idx && d_out, "tstar_nv12_to_rgb: null argument");
+    TSTAR_REQUIRE(N >= 1 && H >= 2 && W >= 2, "tstar_nv12_to_rgb: bad video shape");
+    return nv12_to_rgb_u8(d_video, H, W, d_frame_idx, n, d_out, (hipStream_t)stream);
 }
 
 int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,

@@ -47,9 +47,11 @@ int resample_v_normalize_patchify(const uint8_t* in, float* out, uint8_t* out_u8
 // OpenCV-style fixed-point bilinear resize (11-bit coefficients), gather by frame index.
 // mode 0: frames[idx[i]] (H,W) -> out[i] (oh,ow)
 int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int n, int ow, int oh, uint8_t* out,
-                       hipStream_t s);
+                       int nv12, hipStream_t s);
 // frames[idx[i]] -> (4*ch x 4*cw) -> (ch x cw) -> tile (i / cols, i % cols) of grid [rows*ch, cols*cw, 3]
 int frames_to_grid_u8(const uint8_t* video, int H, int W, const int* d_idx, int rows, int cols, int cw, int ch,
-                      uint8_t* grid, hipStream_t s);
+                      uint8_t* grid, int nv12, hipStream_t s);
+// frames[idx[i]] NV12 [H*3/2, W] -> RGB u8 [n,H,W,3] (BT.601 limited range, nearest chroma)
+int nv12_to_rgb_u8(const uint8_t* video, int H, int W, const int* d_idx, int n, uint8_t* out, hipStream_t s);
 
 }  // namespace tstar

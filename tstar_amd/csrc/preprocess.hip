@@ -203,16 +203,47 @@ static int get_lintab(int src, int dst, const int4** out) {
     return TSTAR_OK;
 }
 
-// one bilinear sample of channel c at output (ox, oy) from an interleaved u8 image
-struct SrcImage { const uint8_t* p; int W; };
-__device__ __forceinline__ int lin_sample(const SrcImage& im, const int4 tx, const int4 ty, int c) {
-    const uint8_t* r0 = im.p + (size_t)ty.x * im.W * 3;
-    const uint8_t* r1 = im.p + (size_t)ty.y * im.W * 3;
-    const int h0 = r0[tx.x * 3 + c] * tx.z + r0[tx.y * 3 + c] * tx.w;
-    const int h1 = r1[tx.x * 3 + c] * tx.z + r1[tx.y * 3 + c] * tx.w;
-    return (((ty.z * (h0 >> 4)) >> 16) + ((ty.w * (h1 >> 4)) >> 16) + 2) >> 2;
+// Source pixel fetch.  RGB frames: interleaved u8 [H, W, 3].  NV12 frames: u8 [H*3/2, W] = luma plane
+// followed by the interleaved half-resolution UV plane; converted on the fly with the BT.601
+// limited-range integer matrix (298/409/100/208/516, >> 8) and nearest chroma (each 2x2 block shares
+// one U,V pair) -- the build's own definition (the reference receives RGB from decord/swscale and never
+// sees NV12).  NV12 halves the bytes per resident frame (345,600 B vs 691,200 B at 360x640).
+struct Rgb { int r, g, b; };
+__device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+struct SrcRGB {
+    const uint8_t* p; int W, H;
+    __device__ __forceinline__ Rgb at(int x, int y) const {
+        const uint8_t* q = p + ((size_t)y * W + x) * 3;
+        return Rgb{q[0], q[1], q[2]};
+    }
+    static __device__ __forceinline__ size_t frame_bytes(int H, int W) { return (size_t)H * W * 3; }
+};
+struct SrcNV12 {
+    const uint8_t* p; int W, H;
+    __device__ __forceinline__ Rgb at(int x, int y) const {
+        const int c = (int)p[(size_t)y * W + x] - 16;
+        const uint8_t* uv = p + (size_t)H * W + (size_t)(y >> 1) * W + (x & ~1);
+        const int d = (int)uv[0] - 128, e = (int)uv[1] - 128;
+        return Rgb{clip255((298 * c + 409 * e + 128) >> 8), clip255((298 * c - 100 * d - 208 * e + 128) >> 8),
+                   clip255((298 * c + 516 * d + 128) >> 8)};
+    }
+    static __device__ __forceinline__ size_t frame_bytes(int H, int W) { return (size_t)H * W * 3 / 2; }
+};
+
+// one bilinear sample (all three channels) at output taps tx, ty
+template <class SRC>
+__device__ __forceinline__ Rgb lin_sample(const SRC& im, const int4 tx, const int4 ty) {
+    const Rgb a = im.at(tx.x, ty.x), b = im.at(tx.y, ty.x), c = im.at(tx.x, ty.y), d = im.at(tx.y, ty.y);
+    auto mix = [&](int p00, int p01, int p10, int p11) {
+        const int h0 = p00 * tx.z + p01 * tx.w;
+        const int h1 = p10 * tx.z + p11 * tx.w;
+        return (((ty.z * (h0 >> 4)) >> 16) + ((ty.w * (h1 >> 4)) >> 16) + 2) >> 2;
+    };
+    return Rgb{mix(a.r, b.r, c.r, d.r), mix(a.g, b.g, c.g, d.g), mix(a.b, b.b, c.b, d.b)};
 }
 
+template <class SRC>
 __global__ __launch_bounds__(256) void bilinear_gather_kernel(const uint8_t* __restrict__ video, int H, int W,
                                                               const int* __restrict__ idx, int ow, int oh,
                                                               const int4* __restrict__ tabx, const int4* __restrict__ taby,
@@ -222,28 +253,29 @@ __global__ __launch_bounds__(256) void bilinear_gather_kernel(const uint8_t* __r
     const int ox = (int)(gid % ow);
     const int oy = (int)((gid / ow) % oh);
     const int i = (int)(gid / ((size_t)ow * oh));
-    SrcImage im{video + (size_t)idx[i] * H * W * 3, W};
-    const int4 tx = tabx[ox], ty = taby[oy];
+    SRC im{video + (size_t)idx[i] * SRC::frame_bytes(H, W), W, H};
+    const Rgb v = lin_sample(im, tabx[ox], taby[oy]);
     uint8_t* d = out + gid * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) d[c] = (uint8_t)lin_sample(im, tx, ty, c);
+    d[0] = (uint8_t)v.r; d[1] = (uint8_t)v.g; d[2] = (uint8_t)v.b;
 }
 
 int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int n, int ow, int oh, uint8_t* out,
-                       hipStream_t s) {
+                       int nv12, hipStream_t s) {
     TSTAR_REQUIRE(n > 0 && ow > 0 && oh > 0, "bilinear_gather_u8: empty output");
     const int4 *tx, *ty;
     int rc = get_lintab(W, ow, &tx); if (rc) return rc;
     rc = get_lintab(H, oh, &ty); if (rc) return rc;
     const size_t total = (size_t)n * ow * oh;
-    hipLaunchKernelGGL(bilinear_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, video, H, W,
-                       d_idx, ow, oh, tx, ty, out, total);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (nv12) hipLaunchKernelGGL(bilinear_gather_kernel<SrcNV12>, grid, dim3(256), 0, s, video, H, W, d_idx, ow, oh, tx, ty, out, total);
+    else hipLaunchKernelGGL(bilinear_gather_kernel<SrcRGB>, grid, dim3(256), 0, s, video, H, W, d_idx, ow, oh, tx, ty, out, total);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
 }
 
 // frame -> (4cw x 4ch) -> (cw x ch), both bilinear with a u8 round trip in between
 // (interface_searcher.py:362 then :186), written straight into its grid cell.
+template <class SRC>
 __global__ __launch_bounds__(256) void frames_to_grid_kernel(const uint8_t* __restrict__ video, int H, int W,
                                                              const int* __restrict__ idx, int cols, int cw, int ch,
                                                              const int4* __restrict__ t1x, const int4* __restrict__ t1y,
@@ -254,23 +286,25 @@ __global__ __launch_bounds__(256) void frames_to_grid_kernel(const uint8_t* __re
     const int ox = (int)(gid % cw);
     const int oy = (int)((gid / cw) % ch);
     const int i = (int)(gid / ((size_t)cw * ch));
-    SrcImage im{video + (size_t)idx[i] * H * W * 3, W};
+    SRC im{video + (size_t)idx[i] * SRC::frame_bytes(H, W), W, H};
     const int4 ax = t2x[ox], ay = t2y[oy];          // taps into the intermediate image
     const int4 x0 = t1x[ax.x], x1 = t1x[ax.y], y0 = t1y[ay.x], y1 = t1y[ay.y];
     const int gr = i / cols, gc = i % cols;
     uint8_t* d = grid + (((size_t)gr * ch + oy) * ((size_t)cols * cw) + (size_t)gc * cw + ox) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int p00 = lin_sample(im, x0, y0, c), p01 = lin_sample(im, x1, y0, c);
-        const int p10 = lin_sample(im, x0, y1, c), p11 = lin_sample(im, x1, y1, c);
-        const int h0 = p00 * ax.z + p01 * ax.w;
-        const int h1 = p10 * ax.z + p11 * ax.w;
-        d[c] = (uint8_t)((((ay.z * (h0 >> 4)) >> 16) + ((ay.w * (h1 >> 4)) >> 16) + 2) >> 2);
-    }
+    const Rgb p00 = lin_sample(im, x0, y0), p01 = lin_sample(im, x1, y0);
+    const Rgb p10 = lin_sample(im, x0, y1), p11 = lin_sample(im, x1, y1);
+    auto mix = [&](int a, int b, int c, int e) {
+        const int h0 = a * ax.z + b * ax.w;
+        const int h1 = c * ax.z + e * ax.w;
+        return (uint8_t)((((ay.z * (h0 >> 4)) >> 16) + ((ay.w * (h1 >> 4)) >> 16) + 2) >> 2);
+    };
+    d[0] = mix(p00.r, p01.r, p10.r, p11.r);
+    d[1] = mix(p00.g, p01.g, p10.g, p11.g);
+    d[2] = mix(p00.b, p01.b, p10.b, p11.b);
 }
 
 int frames_to_grid_u8(const uint8_t* video, int H, int W, const int* d_idx, int rows, int cols, int cw, int ch,
-                      uint8_t* grid, hipStream_t s) {
+                      uint8_t* grid, int nv12, hipStream_t s) {
     TSTAR_REQUIRE(rows > 0 && cols > 0 && cw > 0 && ch > 0, "frames_to_grid_u8: empty grid");
     const int4 *t1x, *t1y, *t2x, *t2y;
     int rc = get_lintab(W, 4 * cw, &t1x); if (rc) return rc;
@@ -278,8 +312,29 @@ int frames_to_grid_u8(const uint8_t* video, int H, int W, const int* d_idx, int 
     rc = get_lintab(4 * cw, cw, &t2x); if (rc) return rc;
     rc = get_lintab(4 * ch, ch, &t2y); if (rc) return rc;
     const size_t total = (size_t)rows * cols * cw * ch;
-    hipLaunchKernelGGL(frames_to_grid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, video, H, W,
-                       d_idx, cols, cw, ch, t1x, t1y, t2x, t2y, grid, total);
+    const dim3 g((unsigned)((total + 255) / 256));
+    if (nv12) hipLaunchKernelGGL(frames_to_grid_kernel<SrcNV12>, g, dim3(256), 0, s, video, H, W, d_idx, cols, cw, ch, t1x, t1y, t2x, t2y, grid, total);
+    else hipLaunchKernelGGL(frames_to_grid_kernel<SrcRGB>, g, dim3(256), 0, s, video, H, W, d_idx, cols, cw, ch, t1x, t1y, t2x, t2y, grid, total);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
+// native-resolution NV12 -> RGB for the frames handed back to the caller (pop_frames)
+__global__ __launch_bounds__(256) void nv12_to_rgb_kernel(const uint8_t* __restrict__ video, int H, int W,
+                                                          const int* __restrict__ idx, uint8_t* __restrict__ out, size_t total) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int x = (int)(gid % W), y = (int)((gid / W) % H), i = (int)(gid / ((size_t)W * H));
+    SrcNV12 im{video + (size_t)idx[i] * SrcNV12::frame_bytes(H, W), W, H};
+    const Rgb v = im.at(x, y);
+    uint8_t* d = out + gid * 3;
+    d[0] = (uint8_t)v.r; d[1] = (uint8_t)v.g; d[2] = (uint8_t)v.b;
+}
+
+int nv12_to_rgb_u8(const uint8_t* video, int H, int W, const int* d_idx, int n, uint8_t* out, hipStream_t s) {
+    TSTAR_REQUIRE(n > 0 && H % 2 == 0 && W % 2 == 0, "nv12_to_rgb_u8: NV12 needs even dimensions");
+    const size_t total = (size_t)n * H * W;
+    hipLaunchKernelGGL(nv12_to_rgb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, video, H, W, d_idx, out, total);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
 }

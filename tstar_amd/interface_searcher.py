@@ -259,7 +259,8 @@ class TStarSearcher:
         grid = torch.empty((rows * CELL_H, cols * CELL_W, 3), dtype=torch.uint8, device=self.store.frames.device)
         idx = self._d_idx(secs)
         _lib.check(self._state.lib.tstar_frames_to_grid(self.store.frames.data_ptr(), N, H, Wd, idx.data_ptr(), rows,
-                                                        cols, grid.data_ptr(), _lib.stream_ptr()), "tstar_frames_to_grid")
+                                                        cols, grid.data_ptr(), int(self.store.fmt == "nv12"),
+                                                        _lib.stream_ptr()), "tstar_frames_to_grid")
         return grid
 
     def _device_verify_frames(self, secs):
@@ -268,7 +269,8 @@ class TStarSearcher:
         out = torch.empty((len(secs), VERIFY_H, VERIFY_W, 3), dtype=torch.uint8, device=self.store.frames.device)
         idx = self._d_idx(secs)
         _lib.check(self._state.lib.tstar_frames_resize(self.store.frames.data_ptr(), N, H, Wd, idx.data_ptr(), len(secs),
-                                                       VERIFY_W, VERIFY_H, out.data_ptr(), _lib.stream_ptr()),
+                                                       VERIFY_W, VERIFY_H, out.data_ptr(), int(self.store.fmt == "nv12"),
+                                                       _lib.stream_ptr()),
                    "tstar_frames_resize")
         return out
 

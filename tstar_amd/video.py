@@ -65,7 +65,13 @@ class FrameStore:
     ``frames`` uint8 cuda tensor [N,H,W,3] with frames[s] = raw frame int(s * raw_fps)
     (the index map of interface_searcher.py:360), plus the raw stream's fps / frame count."""
 
-    def __init__(self, frames, raw_fps: float, raw_total_frames: Optional[int] = None, name: str = "<frames>"):
+    def __init__(self, frames, raw_fps: float, raw_total_frames: Optional[int] = None, name: str = "<frames>",
+                 fmt: str = "rgb"):
+        """``fmt``: "rgb" -> frames u8 [N,H,W,3]; "nv12" -> frames u8 [N, H*3/2, W] (luma plane + interleaved
+        half-resolution UV plane), converted to RGB inside the ingest kernels (half the bytes per frame)."""
+        if fmt not in ("rgb", "nv12"):
+            raise ValueError("FrameStore fmt must be 'rgb' or 'nv12'")
+        self.fmt = fmt
         self.frames = frames
         self.raw_fps = float(raw_fps)
         self.raw_total_frames = int(raw_total_frames if raw_total_frames is not None
@@ -78,11 +84,23 @@ class FrameStore:
 
     @property
     def shape(self):
+        """(N, H, W, 3) of the RGB view, whatever the storage format."""
+        if self.fmt == "nv12":
+            n, h32, w = self.frames.shape
+            return (int(n), int(h32) * 2 // 3, int(w), 3)
         return tuple(self.frames.shape)
 
     def host_frames(self, secs) -> np.ndarray:
-        """Native-resolution frames of the given logical seconds -> uint8 numpy [n,H,W,3]."""
+        """Native-resolution RGB frames of the given logical seconds -> uint8 numpy [n,H,W,3]."""
         import torch
+        if self.fmt == "nv12":
+            from . import _lib
+            N, H, W, _ = self.shape
+            idx = torch.as_tensor([int(i) for i in secs], dtype=torch.int32, device=self.frames.device)
+            out = torch.empty((len(idx), H, W, 3), dtype=torch.uint8, device=self.frames.device)
+            _lib.check(_lib.load().tstar_nv12_to_rgb(self.frames.data_ptr(), N, H, W, idx.data_ptr(), len(idx),
+                                                      out.data_ptr(), _lib.stream_ptr()), "tstar_nv12_to_rgb")
+            return out.cpu().numpy()
         ii = torch.as_tensor([int(i) for i in secs], dtype=torch.long, device=self.frames.device)
         return self.frames.index_select(0, ii).cpu().numpy()
 
@@ -115,6 +133,45 @@ def synthetic_video(n_frames: int = 3600, H: int = 360, W: int = 640, seed: int 
     return FrameStore(frames, raw_fps, None, name=f"synthetic://n={n_frames},h={H},w={W},seed={seed}")
 
 
+def synthetic_nv12_numpy(idx, n_frames: int, H: int = 360, W: int = 640, seed: int = 0) -> np.ndarray:
+    """NV12 variant of the synthetic video (same lattice; channel 0 -> luma, channels 1,2 -> 4:2:0 chroma):
+    uint8 [n, H*3/2, W].  Integer arithmetic only."""
+    rgbish = synthetic_frames_numpy(idx, n_frames, H, W, seed)
+    out = np.empty((len(idx), H * 3 // 2, W), dtype=np.uint8)
+    out[:, :H, :] = 16 + (rgbish[..., 0].astype(np.int32) * 219 // 255).astype(np.uint8)         # limited-range luma
+    uv = rgbish[:, ::2, ::2, 1:3].astype(np.int32)
+    out[:, H:, :] = (16 + uv * 224 // 255).astype(np.uint8).reshape(len(idx), H // 2, W)          # interleaved U,V
+    return out
+
+
+def synthetic_video_nv12(n_frames: int = 3600, H: int = 360, W: int = 640, seed: int = 0, raw_fps: float = 1.0,
+                         device: str = "cuda") -> FrameStore:
+    """NV12 synthetic video in HBM (same bytes as ``synthetic_nv12_numpy``)."""
+    import torch
+    rgb = synthetic_video(n_frames, H, W, seed, raw_fps, device).frames
+    out = torch.empty((n_frames, H * 3 // 2, W), dtype=torch.uint8, device=device)
+    out[:, :H, :] = (16 + torch.div(rgb[..., 0].to(torch.int32) * 219, 255, rounding_mode="floor")).to(torch.uint8)
+    uv = rgb[:, ::2, ::2, 1:3].to(torch.int32)
+    out[:, H:, :] = (16 + torch.div(uv * 224, 255, rounding_mode="floor")).to(torch.uint8).reshape(n_frames, H // 2, W)
+    return FrameStore(out, raw_fps, None, name=f"synthetic://n={n_frames},h={H},w={W},seed={seed},fmt=nv12", fmt="nv12")
+
+
+def load_video_frames(video, num_frames: int = 8) -> np.ndarray:
+    """The grounder's uniform frame loader (/root/reference/TStar/utilites.py:40-81): frames at raw
+    indices floor(i * total / num_frames), RGB uint8 [n,H,W,3] -- served from the resident store (the
+    stored frame nearest in time to each raw index when raw_fps != 1)."""
+    import math
+    st = open_video(video)
+    total = st.raw_total_frames
+    if total == 0:
+        raise ValueError("Video has zero frames or could not retrieve frame count.")
+    n = min(num_frames, total)
+    step = total / n
+    raw = [int(math.floor(i * step)) for i in range(n)]
+    last = st.num_seconds - 1
+    return st.host_frames([min(last, max(0, int(round(r / st.raw_fps)))) for r in raw])
+
+
 _SYN = re.compile(r"^synthetic://")
 
 
@@ -126,6 +183,9 @@ def open_video(video, device: str = "cuda") -> FrameStore:
         return video
     if isinstance(video, str) and _SYN.match(video):
         kv = dict(p.split("=") for p in video[len("synthetic://"):].split(",") if p)
+        if kv.get("fmt", "rgb") == "nv12":
+            return synthetic_video_nv12(int(kv.get("n", 3600)), int(kv.get("h", 360)), int(kv.get("w", 640)),
+                                        int(kv.get("seed", 0)), float(kv.get("fps", 1.0)), device)
         return synthetic_video(int(kv.get("n", 3600)), int(kv.get("h", 360)), int(kv.get("w", 640)),
                                int(kv.get("seed", 0)), float(kv.get("fps", 1.0)), device)
     import torch
