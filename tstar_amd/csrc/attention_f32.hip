@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
             const float* kp = &Ks[cur][l31][4 * h];
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 f32x4 ka = *reinterpret_cast<const f32x4*>(kp + 8 * c);
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
                 for (int e = 0; e < 4; ++e)
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[c][e], s, 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
             // masks + block max
             const int key0 = kb * KB + 4 * h;
             float mb = -INFINITY;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
             // O^T[d][q] += sum_key V[key][d] * P[q][key]
             const float* vp = &Vs[cur][4 * h][l31];
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = (r & 3) + 8 * (r >> 2);
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         if (more) {
 #pragma unroll
