@@ -153,6 +153,9 @@ int tstar_searcher_draw(tstar_searcher* s, const double* h_x, int k, int32_t* h_
 int tstar_searcher_exclude(tstar_searcher* s, const int32_t* h_found, int m, void* stream);
 /* verification overwrites (interface_searcher.py:407): score[secs[i]] = vals[i], in order. */
 int tstar_searcher_set_scores(tstar_searcher* s, const int32_t* h_secs, const double* h_vals, int m, void* stream);
+/* store_score_distribution (interface_searcher.py:207-213): P, score_distribution and non_visiting_frames
+ * copied to h_out f64 [3, N] (in that order) with ONE synchronisation. */
+int tstar_searcher_read_state(tstar_searcher* s, double* h_out, void* stream);
 /* copy a state array to the host: 0 score, 1 non_visiting, 2 P, 3 sampler p, 4 cdf.  Synchronises. */
 int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* stream);
 
@@ -188,7 +191,8 @@ int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int head
                         const uint8_t* d_key_mask, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream, for bench.py's roofline leg.
- * category 0 = gemm_f32_kernel, 1 = attention_f32_kernel.  enable(1) resets the counters;
+ * category 0 = gemm_f32_kernel, 1 = attention_f32_kernel.  enable(n > 0) resets the counters and times every
+ * n-th launch of each category (n = 1: all; a stride co-prime with the 4-GEMM layer pattern samples all shapes);
  * read() synchronises the recorded events and returns launches / total ms / total algorithmic flops. */
 int tstar_prof_enable(int on);
 int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "tstar_searcher_draw": (_i, [_vp, _vp, _i, _vp, _vp]),
     "tstar_searcher_exclude": (_i, [_vp, _vp, _i, _vp]),
     "tstar_searcher_set_scores": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "tstar_searcher_read_state": (_i, [_vp, _vp, _vp]),
     "tstar_searcher_read": (_i, [_vp, _i, _vp, _vp]),
     "tstar_topk_seconds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "tstar_ssim_pairwise": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),

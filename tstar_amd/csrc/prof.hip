@@ -11,6 +11,8 @@ struct Pair { hipEvent_t a, b; double work; };
 struct Cat { std::vector<Pair> pending; std::vector<Pair> pool; long launches = 0; double ms = 0, work = 0; };
 static Cat g_cat[PROF_NCAT];
 static bool g_on = false;
+static int g_stride = 1;            // time every g_stride-th launch of a category
+static long g_seen[PROF_NCAT] = {0, 0};
 static std::mutex g_mu;      // searches may run on several host threads / streams
 
 bool prof_enabled() { return g_on; }
@@ -30,6 +32,8 @@ static void drain(Cat& c) {
 
 void prof_start(int cat, hipStream_t s, double work) {
     std::lock_guard<std::mutex> lk(g_mu);
+    t_last_b[cat] = nullptr;
+    if ((g_seen[cat]++ % g_stride) != 0) return;          // not sampled: prof_stop sees no pending event
     Cat& c = g_cat[cat];
     if (c.pending.size() >= 16384) drain(c);
     Pair p;
@@ -52,7 +56,9 @@ extern "C" {
 int tstar_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
-    for (int i = 0; i < PROF_NCAT; ++i) { drain(g_cat[i]); g_cat[i].launches = 0; g_cat[i].ms = 0; g_cat[i].work = 0; }
+    g_stride = on > 1 ? on : 1;
+    for (int i = 0; i < PROF_NCAT; ++i) {
+        g_seen[i] = 0; drain(g_cat[i]); g_cat[i].launches = 0; g_cat[i].ms = 0; g_cat[i].work = 0; }
     return TSTAR_OK;
 }
 int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops) {

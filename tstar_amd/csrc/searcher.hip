@@ -477,6 +477,17 @@ int tstar_searcher_set_scores(tstar_searcher* s, const int32_t* h_secs, const do
     return TSTAR_OK;
 }
 
+int tstar_searcher_read_state(tstar_searcher* s, double* h_out, void* stream) {
+    TSTAR_REQUIRE(s && h_out, "tstar_searcher_read_state: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nb = (size_t)s->N * sizeof(double);
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h_out, s->P, nb, hipMemcpyDeviceToHost, st));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h_out + s->N, s->score, nb, hipMemcpyDeviceToHost, st));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h_out + 2 * (size_t)s->N, s->unvisited, nb, hipMemcpyDeviceToHost, st));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(st));
+    return TSTAR_OK;
+}
+
 int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* stream) {
     TSTAR_REQUIRE(s && h_out, "tstar_searcher_read: null argument");
     TSTAR_REQUIRE(which >= 0 && which <= 4, "tstar_searcher_read: which must be 0..4");

@@ -97,6 +97,12 @@ class _DeviceState:
         _lib.check(self.lib.tstar_searcher_set_scores(self.h, s.ctypes.data, v.ctypes.data, len(s), _lib.stream_ptr()),
                    "tstar_searcher_set_scores")
 
+    def read_state(self) -> np.ndarray:
+        """[3, N]: P, score_distribution, non_visiting_frames (one synchronisation)."""
+        out = np.empty((3, self.N), dtype=np.float64)
+        _lib.check(self.lib.tstar_searcher_read_state(self.h, out.ctypes.data, _lib.stream_ptr()), "tstar_searcher_read_state")
+        return out
+
     def read(self, which: int) -> np.ndarray:
         out = np.empty(self.N, dtype=np.float64)
         _lib.check(self.lib.tstar_searcher_read(self.h, which, out.ctypes.data, _lib.stream_ptr()), "tstar_searcher_read")
@@ -192,6 +198,8 @@ class TStarSearcher:
     def _choice(self, size: int) -> np.ndarray:
         """numpy legacy RandomState.choice(N, size, replace=False, p) over the device cdf
         (:353-358, :372): MT19937 doubles on the host, searchsorted on the device."""
+        if size > self.total_frame_num:                  # numpy's own check (mtrand choice, replace=False)
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
         found: List[int] = []
         while len(found) < size:
             x = self._uniform(size - len(found))
@@ -276,9 +284,10 @@ class TStarSearcher:
 
     # ---- distribution ----------------------------------------------------------------------------
     def store_score_distribution(self):
-        self.P_history.append(self._state.read(2).tolist())
-        self.Score_history.append(self._state.read(0).tolist())
-        self.non_visiting_history.append(self._state.read(1).tolist())
+        st = self._state.read_state()
+        self.P_history.append(st[0].tolist())
+        self.Score_history.append(st[1].tolist())
+        self.non_visiting_history.append(st[2].tolist())
 
     def _update_from_device(self, secs: List[int], d_conf, overlap=None):
         """update_frame_distribution (:276-321) on the device state; d_conf f64 [rows*cols] (cell i <-> sample i).
