@@ -9,7 +9,10 @@ synthetic video that is already resident in HBM -- BASELINE.json configs[1]: "Sa
 video on 1xMI355X, HIP OWL-ViT-B/32 scorer, batch=256 frames/iter" (grid 16x16).  With N > 1
 (torch.distributed, one rank per GPU, RCCL) every rank searches its own stream of independent
 (video, question) items (weak scaling, no data-path collective) and the final keyframe indices
-are all-gathered once inside the timed region.
+are all-gathered once inside the timed region.  Within a rank, items advance in
+lock-step groups of --lockstep (default 4): iteration t of every item of the group shares one
+detector batch, each image scored against its own question (tstar_amd/lockstep.py); results are
+bit-identical to one-by-one searches.
 
 Prints ONE JSON line on rank 0.  value = candidate frames scored / s over all ranks; a frame
 is scored each time it contributes a confidence to the searcher: g*g per grid call + 1 per
@@ -43,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=16, help="grid side g (g*g frames per iteration)")
-    ap.add_argument("--max-batch", type=int, default=64, help="detector images per forward chunk")
+    ap.add_argument("--max-batch", type=int, default=128, help="detector images per forward chunk")
     ap.add_argument("--nframes", type=int, default=N_FRAMES)
     ap.add_argument("--search-nframes", type=int, default=8)
     ap.add_argument("--weights", choices=["f32", "bf16"], default="f32",
@@ -53,18 +56,29 @@ def parse():
                     help="independent searches in flight per GPU (host threads, one HIP stream + one scorer "
                          "workspace each); 2 fills kernel tails and gives ~+11 % throughput, but overlapping "
                          "launches inflate per-launch durations, so the roofline leg is reported at 1")
+    ap.add_argument("--lockstep", type=int, default=4,
+                    help="independent (video, question) items advanced in lock-step per detector batch "
+                         "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
 
-def run_search(heuristic, store, g, seed, k=8):
+def make_searcher(heuristic, store, g, seed, k=8):
     from tstar_amd.interface_searcher import TStarSearcher
-    s = TStarSearcher(store, heuristic, list(TARGETS), list(CUES), search_nframes=k, image_grid_shape=(g, g),
-                      search_budget=1000, confidence_threshold=0.6, rng=np.random.RandomState(seed),
-                      keep_visual_history=False)
-    _, ts = s.search()
-    return s, ts
+    return TStarSearcher(store, heuristic, list(TARGETS), list(CUES), search_nframes=k, image_grid_shape=(g, g),
+                         search_budget=1000, confidence_threshold=0.6, rng=np.random.RandomState(seed),
+                         keep_visual_history=False)
+
+
+def run_group(heuristic, store, g, seeds, k=8):
+    """One lock-step group of independent searches (a single search when len(seeds) == 1)."""
+    from tstar_amd.lockstep import search_lockstep
+    ss = [make_searcher(heuristic, store, g, sd, k) for sd in seeds]
+    if len(ss) == 1:
+        return [(ss[0], ss[0].search()[1])]
+    res = search_lockstep(ss)
+    return [(s_, r[1]) for s_, r in zip(ss, res)]
 
 
 def cpu_baseline(args, stats):
@@ -153,8 +167,9 @@ def main():
     def run_many(seeds):
         """Run one search per seed, `conc` at a time; returns per-search (searcher, timestamps, seconds)."""
         q = queue.Queue()
-        for i, sd in enumerate(seeds):
-            q.put((i, sd))
+        L = max(1, min(args.lockstep, 15))
+        for i in range(0, len(seeds), L):
+            q.put((i, seeds[i:i + L]))
         out = [None] * len(seeds)
         errs = []
 
@@ -168,9 +183,10 @@ def main():
                         except queue.Empty:
                             break
                         t1 = time.perf_counter()
-                        s_, ts_ = run_search(heuristics[w], store, g, sd, args.search_nframes)
+                        grp = run_group(heuristics[w], store, g, sd, args.search_nframes)
                         streams[w].synchronize()
-                        out[i] = (s_, ts_, time.perf_counter() - t1)
+                        for j, (s_, ts_) in enumerate(grp):
+                            out[i + j] = (s_, ts_, time.perf_counter() - t1)
             except Exception as e:                      # surface worker failures in the main thread
                 errs.append(e)
 
@@ -240,7 +256,7 @@ def main():
                 "workload": f"{'configs[1]' if args.weights == 'f32' and args.nframes == N_FRAMES else 'variant'}: {args.nframes}-frame {FRAME_H}x{FRAME_W} synthetic RGB video resident in HBM, 1 question "
                             f"(targets {TARGETS}, cues {CUES}), OWL-ViT-B/32 {args.weights} weights (seeded synthetic), grid {g}x{g} = "
                             f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
-                "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc,
+                "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc, "lockstep_items_per_batch": max(1, min(args.lockstep, 15)),
                 "mean_search_latency_sec": latency,
                 "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,
                 "detector_images_per_video": images / args.steps, "max_batch": args.max_batch,

@@ -38,6 +38,7 @@ extern "C" {
 #define TSTAR_OWL_QDIM 512
 #define TSTAR_OWL_TEXT_LEN 16
 #define TSTAR_OWL_MAX_QUERIES 32
+#define TSTAR_OWL_MAX_SETS 16      /* independent query sets (questions) resident at once */
 
 const char* tstar_last_error(void);
 int tstar_abi_version(void);
@@ -69,23 +70,27 @@ int tstar_owl_destroy(tstar_owl* h);
  * detector call (interface_heuristic.py:234,239 -> HF modeling_owlvit.py:945-958, 631-663):
  * runs the CLIP text tower once for Q queries (ids/mask int32 [Q,16]) and keeps the
  * L2-normalised query embeddings resident.  h_class_weight [Q] = object2weight of each
- * query's name (interface_searcher.py:88-91,136).  Synchronises `stream`. */
-int tstar_owl_set_queries(tstar_owl* h, const int32_t* h_input_ids, const int32_t* h_attention_mask,
+ * query's name (interface_searcher.py:88-91,136).  `query_set` (0..15) is the slot the queries are stored
+ * in: several (video, question) items can be resident at once and every image of a tstar_owl_score call
+ * names the slot it is scored against (the reference keeps exactly one query set, = slot 0).
+ * Synchronises `stream`. */
+int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_input_ids, const int32_t* h_attention_mask,
                           const float* h_class_weight, int Q, void* stream);
 /* Same, from precomputed L2-normalised embeddings float32 [Q,512] and query mask u8 [Q]. */
-int tstar_owl_set_query_embeds(tstar_owl* h, const float* h_query_embeds, const uint8_t* h_query_mask,
+int tstar_owl_set_query_embeds(tstar_owl* h, int query_set, const float* h_query_embeds, const uint8_t* h_query_mask,
                                const float* h_class_weight, int Q, void* stream);
 /* Replaces only the per-query class weights (TStarSearcher sets object2weight AFTER it has
  * reparameterised the heuristic, interface_searcher.py:87-91). */
-int tstar_owl_set_class_weights(tstar_owl* h, const float* h_class_weight, int Q, void* stream);
+int tstar_owl_set_class_weights(tstar_owl* h, int query_set, const float* h_class_weight, int Q, void* stream);
 /* Copies the resident (L2-normalised, pre-class-head) query embeddings float32 [Q,512] to the host. */
-int tstar_owl_get_query_embeds(tstar_owl* h, float* h_out, int Q, void* stream);
+int tstar_owl_get_query_embeds(tstar_owl* h, int query_set, float* h_out, int Q, void* stream);
 
 /* Replaces OWLInterface.inference_detector (interface_heuristic.py:232-246: HF preprocess,
  * both towers' forward, post_process_grounded_object_detection(threshold=0.005)) AND the
  * detection->grid-cell loop of TStarSearcher.imageGridScoreFunction
  * (interface_searcher.py:129-150) for B images of identical size in one call.
  *   d_images      u8  [B,H,W,3] RGB (the grid image, or a verification frame)
+ *   h_image_query_set  i32 [B] (host) query set of every image, or NULL (all images use set 0)
  *   d_scores      f32 [B,576]   sigmoid(max_q logit)            (dense: not thresholded)
  *   d_labels      i32 [B,576]   argmax_q logit
  *   d_boxes_xyxy  f32 [B,576,4] pixels of the passed image
@@ -93,11 +98,11 @@ int tstar_owl_get_query_embeds(tstar_owl* h, float* h_out, int Q, void* stream);
  *                                    score * class_weight[label], row-major cells; 0 if none
  *   d_cell_mask   u32 [B,rows*cols]  bit q set <=> a kept detection with label q fell in the cell
  *   d_n_kept      i32 [B]       number of detections with score > 0.005 (may be NULL)
- *   d_logits      f32 [B,576,Q] raw logits (may be NULL)
+ *   d_logits      f32 [B,576,Q] raw logits (may be NULL; needs the same Q for every image)
  *   d_boxes_cxcywh f32 [B,576,4] pred_boxes (may be NULL)
  */
 int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
-                    float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
+                    const int32_t* h_image_query_set, float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
                     uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits, float* d_boxes_cxcywh, void* stream);
 
 /* Diagnostics for parity tests: the preprocessed 768x768 u8 image of the LAST chunk's image 0

@@ -386,3 +386,57 @@ def test_config5_four_hour_video_bf16_weights():
     # rounding really happened: a weight matrix holds only bf16-representable values
     m = sd["owlvit.vision_model.encoder.layers.0.mlp.fc1.weight"]
     assert np.all((m.view(np.uint32) & 0xFFFF) == 0)
+
+
+def test_lockstep_group_equals_sequential_searches():
+    """Several (video, question) items advanced in lock-step (one detector batch per iteration, each image
+    scored against its own query set) give bit-identical results to one-by-one searches."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.lockstep import search_lockstep
+    from tstar_amd.video import synthetic_video, synthetic_video_nv12
+    h = OWLInterface(synthetic_seed=0, max_batch=16)
+    stores = [synthetic_video(160, seed=21), synthetic_video_nv12(200, seed=22), synthetic_video(120, seed=23)]
+    items = [dict(t=["couch"], c=["tv", "chair"], K=4, b=0.4), dict(t=["dog", "lamp"], c=[], K=6, b=0.3),
+             dict(t=["a red car"], c=["road"], K=3, b=0.5)]
+
+    def make(i, keep=False):
+        it = items[i]
+        return TStarSearcher(stores[i], h, list(it["t"]), list(it["c"]), search_nframes=it["K"], image_grid_shape=(4, 4),
+                             search_budget=it["b"], confidence_threshold=0.6, rng=np.random.RandomState(100 + i),
+                             keep_visual_history=keep)
+
+    seq = []
+    for i in range(3):
+        s = make(i)
+        fr, ts = s.search()
+        seq.append((fr, ts, s.score_distribution, s.frames_scored, s.detector_calls, s.iterations, s.P_history[-1]))
+    group = [make(i, keep=(i == 0)) for i in range(3)]
+    res = search_lockstep(group)
+    for i in range(3):
+        assert res[i][1] == seq[i][1] and np.array_equal(res[i][0], seq[i][0])
+        assert np.array_equal(group[i].score_distribution, seq[i][2])
+        assert (group[i].frames_scored, group[i].detector_calls, group[i].iterations) == seq[i][3:6]
+        assert group[i].P_history[-1] == seq[i][6]
+    assert len(group[0].image_grid_iters) == len(group[0].detect_annotot_iters) > 0
+    with pytest.raises(ValueError, match="own rng"):
+        search_lockstep([TStarSearcher(stores[0], h, ["a"], [], image_grid_shape=(4, 4))])
+
+
+def test_query_sets_are_independent():
+    """Per-image query sets: a batch scored against slots 1 and 2 equals two single-slot calls."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    h = OWLInterface(synthetic_seed=0, max_batch=4)
+    h.install_queries(1, ["couch"], ["tv"])
+    h.install_queries(2, ["a big dog", "cat"], ["tree", "road", "sky"])
+    img = torch.randint(0, 255, (2, 285, 600, 3), dtype=torch.uint8, device="cuda")
+    both = h.score_batch(img, 1, 1, image_sets=[1, 2])
+    a = h.score_batch(img[:1], 1, 1, image_sets=[1])
+    b = h.score_batch(img[1:], 1, 1, image_sets=[2])
+    torch.cuda.synchronize()
+    assert torch.equal(both.scores[0], a.scores[0]) and torch.equal(both.scores[1], b.scores[0])
+    assert torch.equal(both.labels[1], b.labels[0]) and torch.equal(both.cell_conf[1], b.cell_conf[0])
+    assert int(both.labels[1].max()) <= 5 and int(both.labels[0].max()) <= 2
+    from tstar_amd import _lib
+    with pytest.raises(_lib.TStarHipError, match="no queries installed"):
+        h.score_batch(img, 1, 1, image_sets=[1, 7])

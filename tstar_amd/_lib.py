@@ -27,11 +27,11 @@ SIGNATURES = {
     "tstar_owl_text_blob_floats": (_sz, []),
     "tstar_owl_create": (_i, [C.POINTER(_vp), _vp, _sz, _vp, _sz, _vp, _i, _i]),
     "tstar_owl_destroy": (_i, [_vp]),
-    "tstar_owl_set_queries": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
-    "tstar_owl_set_query_embeds": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
-    "tstar_owl_set_class_weights": (_i, [_vp, _vp, _i, _vp]),
-    "tstar_owl_get_query_embeds": (_i, [_vp, _vp, _i, _vp]),
-    "tstar_owl_score": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tstar_owl_set_queries": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "tstar_owl_set_query_embeds": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "tstar_owl_set_class_weights": (_i, [_vp, _i, _vp, _i, _vp]),
+    "tstar_owl_get_query_embeds": (_i, [_vp, _i, _vp, _i, _vp]),
+    "tstar_owl_score": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tstar_owl_debug_preprocess": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tstar_frames_to_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "tstar_frames_resize": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp]),

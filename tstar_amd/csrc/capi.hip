@@ -67,10 +67,13 @@ struct tstar_owl {
     // activation workspace (per chunk of max_batch images)
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
     uint8_t* tmp_u8 = nullptr; size_t tmp_u8_bytes = 0;
-    // queries
-    int Q = 0;
-    float *q_raw = nullptr, *qn = nullptr, *qweight = nullptr;
-    uint8_t* qmask = nullptr;
+    // query sets: TSTAR_OWL_MAX_SETS independent (question) slots, each up to 32 queries; every image of
+    // a score call names the slot it is scored against (several (video, question) items batched together)
+    int Q[TSTAR_OWL_MAX_SETS] = {0};
+    float *q_raw = nullptr, *qn = nullptr, *qweight = nullptr;       // [sets][32][512] / [sets][32]
+    uint8_t* qmask = nullptr;                                        // [sets][32]
+    int *d_setQ = nullptr, *d_image_set = nullptr;
+    int image_set_cap = 0;
     int *d_ids = nullptr, *d_eos = nullptr;
     uint8_t* d_kmask = nullptr;
     std::map<int, ResampleTable> tabs;   // in_size -> table to 768
@@ -238,9 +241,13 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
     alloc(&h->x, mp * V_D); alloc(&h->xn, mp * V_D); alloc(&h->qkv, mp * 3 * V_D); alloc(&h->att, mp * V_D);
     alloc(&h->hid, mp * V_FF);
     alloc(&h->d_lut, 768);
-    alloc(&h->q_raw, TSTAR_OWL_MAX_QUERIES * PROJ); alloc(&h->qn, TSTAR_OWL_MAX_QUERIES * PROJ);
-    alloc(&h->qweight, TSTAR_OWL_MAX_QUERIES);
-    if (e == hipSuccess) e = hipMalloc(&h->qmask, TSTAR_OWL_MAX_QUERIES);
+    constexpr int NSQ = TSTAR_OWL_MAX_SETS * TSTAR_OWL_MAX_QUERIES;
+    alloc(&h->q_raw, (size_t)NSQ * PROJ); alloc(&h->qn, (size_t)NSQ * PROJ);
+    alloc(&h->qweight, NSQ);
+    if (e == hipSuccess) e = hipMalloc(&h->qmask, NSQ);
+    if (e == hipSuccess) e = hipMemset(h->qmask, 0, NSQ);
+    if (e == hipSuccess) e = hipMalloc(&h->d_setQ, TSTAR_OWL_MAX_SETS * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->d_setQ, 0, TSTAR_OWL_MAX_SETS * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->d_ids, TSTAR_OWL_MAX_QUERIES * T_LEN * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->d_eos, TSTAR_OWL_MAX_QUERIES * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->d_kmask, TSTAR_OWL_MAX_QUERIES * T_LEN);
@@ -261,7 +268,7 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
 int tstar_owl_destroy(tstar_owl* h) {
     if (!h) return TSTAR_OK;
     void* ptrs[] = {h->d_vision, h->d_text, h->d_lut, h->x, h->xn, h->qkv, h->att, h->hid, h->tmp_u8, h->q_raw,
-                    h->qn, h->qweight, h->qmask, h->d_ids, h->d_eos, h->d_kmask};
+                    h->qn, h->qweight, h->qmask, h->d_ids, h->d_eos, h->d_kmask, h->d_setQ, h->d_image_set};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : h->tabs) free_table(&kv.second);
     for (auto& kv : h->wb) if (kv.second) (void)hipFree(kv.second);
@@ -269,19 +276,24 @@ int tstar_owl_destroy(tstar_owl* h) {
     return TSTAR_OK;
 }
 
-static int finish_queries(tstar_owl* h, const uint8_t* h_mask, const float* h_w, int Q, hipStream_t s) {
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->q_raw, h->qn, 1e-6f);
+#define CHECK_SET(set, fn) TSTAR_REQUIRE((set) >= 0 && (set) < TSTAR_OWL_MAX_SETS, fn ": query_set must be in 0..15")
+
+static int finish_queries(tstar_owl* h, int set, const uint8_t* h_mask, const float* h_w, int Q, hipStream_t s) {
+    const size_t qo = (size_t)set * TSTAR_OWL_MAX_QUERIES;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->q_raw + qo * PROJ, h->qn + qo * PROJ, 1e-6f);
     TSTAR_HIP_CHECK(hipGetLastError());
-    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qmask, h_mask, Q, hipMemcpyHostToDevice, s));
-    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight, h_w, Q * sizeof(float), hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qmask + qo, h_mask, Q, hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight + qo, h_w, Q * sizeof(float), hipMemcpyHostToDevice, s));
+    h->Q[set] = Q;
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_setQ, h->Q, sizeof(h->Q), hipMemcpyHostToDevice, s));
     TSTAR_HIP_CHECK(hipStreamSynchronize(s));
-    h->Q = Q;
     return TSTAR_OK;
 }
 
-int tstar_owl_set_queries(tstar_owl* h, const int32_t* h_ids, const int32_t* h_am, const float* h_w, int Q,
+int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_ids, const int32_t* h_am, const float* h_w, int Q,
                           void* stream) {
     TSTAR_REQUIRE(h && h_ids && h_am && h_w, "tstar_owl_set_queries: null argument");
+    CHECK_SET(query_set, "tstar_owl_set_queries");
     TSTAR_REQUIRE(Q >= 1 && Q <= TSTAR_OWL_MAX_QUERIES, "tstar_owl_set_queries: Q must be in 1..32");
     if (!h->has_text) { set_error("tstar_owl_set_queries: handle was created without text weights"); return TSTAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
@@ -310,47 +322,71 @@ int tstar_owl_set_queries(tstar_owl* h, const int32_t* h_ids, const int32_t* h_a
     hipLaunchKernelGGL(gather_rows_kernel, dim3(Q), dim3(128), 0, s, h->xn, h->d_eos, h->att, T_LEN, T_D);
     TSTAR_HIP_CHECK(hipGetLastError());
     RC(gemm_f32(mk_gemm(h, h->att, h->tw.text_proj, h->hid, nullptr, nullptr, Q, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->hid, h->q_raw, 0.0f);
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->hid,
+                       h->q_raw + (size_t)query_set * TSTAR_OWL_MAX_QUERIES * PROJ, 0.0f);
     TSTAR_HIP_CHECK(hipGetLastError());
-    return finish_queries(h, qm.data(), h_w, Q, s);
+    return finish_queries(h, query_set, qm.data(), h_w, Q, s);
 }
 
-int tstar_owl_set_query_embeds(tstar_owl* h, const float* h_qe, const uint8_t* h_mask, const float* h_w, int Q,
-                               void* stream) {
+int tstar_owl_set_query_embeds(tstar_owl* h, int query_set, const float* h_qe, const uint8_t* h_mask, const float* h_w,
+                               int Q, void* stream) {
     TSTAR_REQUIRE(h && h_qe && h_mask && h_w, "tstar_owl_set_query_embeds: null argument");
+    CHECK_SET(query_set, "tstar_owl_set_query_embeds");
     TSTAR_REQUIRE(Q >= 1 && Q <= TSTAR_OWL_MAX_QUERIES, "tstar_owl_set_query_embeds: Q must be in 1..32");
     hipStream_t s = (hipStream_t)stream;
-    TSTAR_HIP_CHECK(hipMemcpyAsync(h->q_raw, h_qe, (size_t)Q * PROJ * sizeof(float), hipMemcpyHostToDevice, s));
-    return finish_queries(h, h_mask, h_w, Q, s);
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->q_raw + (size_t)query_set * TSTAR_OWL_MAX_QUERIES * PROJ, h_qe,
+                                   (size_t)Q * PROJ * sizeof(float), hipMemcpyHostToDevice, s));
+    return finish_queries(h, query_set, h_mask, h_w, Q, s);
 }
 
-int tstar_owl_set_class_weights(tstar_owl* h, const float* h_w, int Q, void* stream) {
+int tstar_owl_set_class_weights(tstar_owl* h, int query_set, const float* h_w, int Q, void* stream) {
     TSTAR_REQUIRE(h && h_w, "tstar_owl_set_class_weights: null argument");
-    TSTAR_REQUIRE(Q == h->Q && Q >= 1, "tstar_owl_set_class_weights: Q does not match the installed queries");
+    CHECK_SET(query_set, "tstar_owl_set_class_weights");
+    TSTAR_REQUIRE(Q == h->Q[query_set] && Q >= 1, "tstar_owl_set_class_weights: Q does not match the installed queries");
     hipStream_t s = (hipStream_t)stream;
-    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight, h_w, Q * sizeof(float), hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight + (size_t)query_set * TSTAR_OWL_MAX_QUERIES, h_w, Q * sizeof(float),
+                                   hipMemcpyHostToDevice, s));
     TSTAR_HIP_CHECK(hipStreamSynchronize(s));
     return TSTAR_OK;
 }
 
-int tstar_owl_get_query_embeds(tstar_owl* h, float* h_out, int Q, void* stream) {
+int tstar_owl_get_query_embeds(tstar_owl* h, int query_set, float* h_out, int Q, void* stream) {
     TSTAR_REQUIRE(h && h_out, "tstar_owl_get_query_embeds: null argument");
-    TSTAR_REQUIRE(Q == h->Q, "tstar_owl_get_query_embeds: Q does not match the installed queries");
+    CHECK_SET(query_set, "tstar_owl_get_query_embeds");
+    TSTAR_REQUIRE(Q == h->Q[query_set], "tstar_owl_get_query_embeds: Q does not match the installed queries");
     hipStream_t s = (hipStream_t)stream;
-    TSTAR_HIP_CHECK(hipMemcpyAsync(h_out, h->q_raw, (size_t)Q * PROJ * sizeof(float), hipMemcpyDeviceToHost, s));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h_out, h->q_raw + (size_t)query_set * TSTAR_OWL_MAX_QUERIES * PROJ,
+                                   (size_t)Q * PROJ * sizeof(float), hipMemcpyDeviceToHost, s));
     TSTAR_HIP_CHECK(hipStreamSynchronize(s));
     return TSTAR_OK;
 }
 
 int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
-                    float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
+                    const int32_t* h_image_query_set, float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
                     uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits, float* d_boxes_cxcywh, void* stream) {
     TSTAR_REQUIRE(h && d_images && d_scores && d_labels && d_boxes_xyxy && d_cell_conf && d_cell_mask,
                   "tstar_owl_score: null argument");
     TSTAR_REQUIRE(B >= 1 && H >= 1 && W >= 1, "tstar_owl_score: empty batch or image");
     TSTAR_REQUIRE(grid_rows >= 1 && grid_cols >= 1, "tstar_owl_score: grid must be at least 1x1");
-    if (h->Q == 0) { set_error("tstar_owl_score: no queries installed (call tstar_owl_set_queries first)"); return TSTAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
+    int q_uniform = -1;                                   // the common Q when every image uses one set size
+    for (int b = 0; b < B; ++b) {
+        const int set = h_image_query_set ? h_image_query_set[b] : 0;
+        CHECK_SET(set, "tstar_owl_score");
+        if (h->Q[set] == 0) { set_error("tstar_owl_score: no queries installed in the requested query set (call tstar_owl_set_queries first)"); return TSTAR_ERR_STATE; }
+        q_uniform = (b == 0 || q_uniform == h->Q[set]) ? h->Q[set] : 0;
+    }
+    TSTAR_REQUIRE(!d_logits || q_uniform > 0, "tstar_owl_score: raw logits need the same query count for every image");
+    if (h_image_query_set) {
+        if (B > h->image_set_cap) {
+            TSTAR_HIP_CHECK(hipStreamSynchronize(s));
+            if (h->d_image_set) TSTAR_HIP_CHECK(hipFree(h->d_image_set));
+            h->d_image_set = nullptr; h->image_set_cap = 0;
+            TSTAR_HIP_CHECK(hipMalloc(&h->d_image_set, (size_t)B * sizeof(int)));
+            h->image_set_cap = B;
+        }
+        TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_image_set, h_image_query_set, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+    }
     const int ncell = grid_rows * grid_cols;
     for (int b0 = 0; b0 < B; b0 += h->max_batch) {
         const int Bc = (B - b0) < h->max_batch ? (B - b0) : h->max_batch;
@@ -377,11 +413,13 @@ int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, 
         a.scores = d_scores + (size_t)b0 * V_NP;
         a.labels = d_labels + (size_t)b0 * V_NP;
         a.xyxy = d_boxes_xyxy + (size_t)b0 * V_NP * 4;
-        a.logits = d_logits ? d_logits + (size_t)b0 * V_NP * h->Q : nullptr;
+        a.logits = d_logits ? d_logits + (size_t)b0 * V_NP * q_uniform : nullptr;
+        a.image_set = h_image_query_set ? h->d_image_set + b0 : nullptr;
+        a.setQ = h->d_setQ;
         a.cxcywh = d_boxes_cxcywh ? d_boxes_cxcywh + (size_t)b0 * V_NP * 4 : nullptr;
-        a.rows = MP; a.np = V_NP; a.Q = h->Q; a.img_w = W; a.img_h = H;
+        a.rows = MP; a.np = V_NP; a.Q = q_uniform; a.img_w = W; a.img_h = H;
         RC(detect_rows(a, s));
-        RC(cell_reduce(a.scores, a.labels, a.xyxy, h->qweight, Bc, V_NP, W, H, grid_rows, grid_cols, 0.005f,
+        RC(cell_reduce(a.scores, a.labels, a.xyxy, h->qweight, a.image_set, Bc, V_NP, W, H, grid_rows, grid_cols, 0.005f,
                        d_cell_conf + (size_t)b0 * ncell, d_cell_mask + (size_t)b0 * ncell,
                        d_n_kept ? d_n_kept + b0 : nullptr, s));
     }

@@ -8,8 +8,10 @@ struct DetectRowsArgs {
     const float* feats;    // [rows, 768]  image feats after detection LayerNorm
     const float* cls;      // [rows, 512]  class_head.dense0 output
     const float* boxh;     // [rows, 768]  box_head after dense1 + GELU
-    const float* qn;       // [Q, 512]     query embeds / (||q|| + 1e-6)
-    const uint8_t* qmask;  // [Q]          0 = padded query
+    const float* qn;       // [sets][32][512]  query embeds / (||q|| + 1e-6)
+    const uint8_t* qmask;  // [sets][32]       0 = padded query
+    const int* image_set;  // [B] query set of every image, or null (all images use set 0)
+    const int* setQ;       // [sets] number of queries per set
     const float* shift_w; const float* shift_b;
     const float* scale_w; const float* scale_b;
     const float* box2_w;   // [4, 768]
@@ -20,11 +22,11 @@ struct DetectRowsArgs {
     float* xyxy;           // [rows, 4] pixels of the passed image
     float* logits;         // [rows, Q] or null
     float* cxcywh;         // [rows, 4] or null
-    int rows, np, Q, img_w, img_h;
+    int rows, np, Q, img_w, img_h;   // Q: common query count (row stride of `logits`), 0 if the sets differ
 };
 int detect_rows(const DetectRowsArgs& a, hipStream_t s);
 
-int cell_reduce(const float* scores, const int* labels, const float* xyxy, const float* qweight, int B, int np,
+int cell_reduce(const float* scores, const int* labels, const float* xyxy, const float* qweight, const int* image_set, int B, int np,
                 int img_w, int img_h, int grows, int gcols, float thr, double* cell_conf, uint32_t* cell_mask,
                 int* n_kept, hipStream_t s);
 

@@ -65,19 +65,23 @@ __global__ __launch_bounds__(256) void detect_rows_kernel(DetectRowsArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) c[i][e] = c[i][e] / den;
 
+    const int set = a.image_set ? a.image_set[row / a.np] : 0;
+    const int nq = a.setQ[set];
+    const float* qn = a.qn + (size_t)set * 32 * 512;
+    const uint8_t* qmask = a.qmask + set * 32;
     float best = -FLT_MAX;
     int label = 0;
-    for (int q = 0; q < a.Q; ++q) {
+    for (int q = 0; q < nq; ++q) {
         float d = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(a.qn + (size_t)q * 512 + (i * 64 + lane) * 4);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(qn + (size_t)q * 512 + (i * 64 + lane) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) d += c[i][e] * qv[e];
         }
         d = wsum(d);
         float lg = (d + sh) * sc;
-        if (a.qmask[q] == 0) lg = -FLT_MAX;             // torch.finfo(float32).min
+        if (qmask[q] == 0) lg = -FLT_MAX;               // torch.finfo(float32).min
         if (a.logits && lane == 0) a.logits[(size_t)row * a.Q + q] = lg;
         if (lg > best) { best = lg; label = q; }        // ties -> lowest index (torch CPU max)
     }
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void detect_rows_kernel(DetectRowsArgs a) {
 }
 
 int detect_rows(const DetectRowsArgs& a, hipStream_t s) {
-    TSTAR_REQUIRE(a.rows > 0 && a.Q > 0, "detect_rows: empty problem");
+    TSTAR_REQUIRE(a.rows > 0 && a.setQ, "detect_rows: empty problem");
     hipLaunchKernelGGL(detect_rows_kernel, dim3(cdiv(a.rows, 4)), dim3(256), 0, s, a);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
@@ -125,8 +129,8 @@ int detect_rows(const DetectRowsArgs& a, hipStream_t s) {
 
 // One block per image.  conf is >= 0, so max over f32 == max over its bit pattern.
 __global__ __launch_bounds__(256) void cell_reduce_kernel(const float* __restrict__ scores, const int* __restrict__ labels,
-                                                          const float* __restrict__ xyxy, const float* __restrict__ qweight,
-                                                          int np, int img_w, int img_h, int grows, int gcols, float thr,
+                                                          const float* __restrict__ xyxy, const float* __restrict__ qweight_all,
+                                                          const int* __restrict__ image_set, int np, int img_w, int img_h, int grows, int gcols, float thr,
                                                           double* __restrict__ cell_conf, uint32_t* __restrict__ cell_mask,
                                                           int* __restrict__ n_kept) {
     extern __shared__ uint32_t sm[];
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(256) void cell_reduce_kernel(const float* __restric
     uint32_t* cmask = sm + ncell;
     __shared__ int kept;
     const int b = blockIdx.x;
+    const float* qweight = qweight_all + (image_set ? image_set[b] : 0) * 32;
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) { cbits[i] = 0u; cmask[i] = 0u; }
     if (threadIdx.x == 0) kept = 0;
     __syncthreads();
@@ -167,12 +172,12 @@ __global__ __launch_bounds__(256) void cell_reduce_kernel(const float* __restric
     if (threadIdx.x == 0 && n_kept) n_kept[b] = kept;
 }
 
-int cell_reduce(const float* scores, const int* labels, const float* xyxy, const float* qweight, int B, int np,
-                int img_w, int img_h, int grows, int gcols, float thr, double* cell_conf, uint32_t* cell_mask,
+int cell_reduce(const float* scores, const int* labels, const float* xyxy, const float* qweight, const int* image_set,
+                int B, int np, int img_w, int img_h, int grows, int gcols, float thr, double* cell_conf, uint32_t* cell_mask,
                 int* n_kept, hipStream_t s) {
     TSTAR_REQUIRE(grows > 0 && gcols > 0 && grows * gcols <= 4096, "cell_reduce: grid must have 1..4096 cells");
     const size_t lds = (size_t)grows * gcols * 2 * sizeof(uint32_t);
-    hipLaunchKernelGGL(cell_reduce_kernel, dim3(B), dim3(256), lds, s, scores, labels, xyxy, qweight, np, img_w, img_h,
+    hipLaunchKernelGGL(cell_reduce_kernel, dim3(B), dim3(256), lds, s, scores, labels, xyxy, qweight, image_set, np, img_w, img_h,
                        grows, gcols, thr, cell_conf, cell_mask, n_kept);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;

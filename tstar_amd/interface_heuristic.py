@@ -135,9 +135,27 @@ class OWLInterface(HeuristicInterface):
         self.scorer.set_class_weights(w)
         self._class_weight = np.asarray(w, dtype=np.float32)
 
-    def score_batch(self, d_images, grid_rows: int, grid_cols: int):
-        """Batched scoring of device images u8 [B,H,W,3] -> tstar_amd.owl.ScoreResult (device tensors)."""
-        return self.scorer.score(d_images, grid_rows, grid_cols)
+    def score_batch(self, d_images, grid_rows: int, grid_cols: int, image_sets=None):
+        """Batched scoring of device images u8 [B,H,W,3] -> tstar_amd.owl.ScoreResult (device tensors).
+        ``image_sets``: query-set slot per image (see ``install_queries``); default slot 0."""
+        return self.scorer.score(d_images, grid_rows, grid_cols, image_sets=image_sets)
+
+    def install_queries(self, slot: int, target_objects: List[str], cue_objects: List[str],
+                        object2weight: Optional[Dict[str, float]] = None) -> List[List[str]]:
+        """Install a question's queries in slot 1..15 WITHOUT touching ``self.texts`` (slot 0 is what
+        ``reparameterize_object_list`` manages).  Several (video, question) items can then be scored in
+        one batch, each image against its own slot.  Returns the texts list of the slot."""
+        if not 1 <= int(slot) <= 15:
+            raise ValueError("install_queries: slot must be in 1..15")
+        texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
+        ids, am = encode_queries(texts, self.model_name_or_path)
+        o2w = dict(object2weight or {})
+        for o in target_objects:
+            o2w.setdefault(o, 1.0)
+        for o in cue_objects:
+            o2w.setdefault(o, 0.5)
+        self.scorer.set_queries(ids, am, [float(o2w.get(t[0], 0.5)) for t in texts], slot=int(slot))
+        return texts
 
     def _detections_from(self, r, b: int) -> Detections:
         s = r.scores[b].cpu().numpy()

@@ -170,6 +170,7 @@ class TStarSearcher:
         self._fast = hasattr(heuristic, "score_batch") and hasattr(heuristic, "set_class_weights")
         if self._fast:
             heuristic.set_class_weights(self.object2weight)
+        self._texts = [list(t) for t in heuristic.texts]      # this searcher's class names (label -> name)
 
         self._rng = rng
         self.keep_visual_history = keep_visual_history
@@ -212,7 +213,7 @@ class TStarSearcher:
         return np.asarray(found[:size], dtype=np.int64)
 
     def _names_from_mask(self, mask: int) -> List[str]:
-        return [self.heuristic.texts[q][0] for q in range(len(self.heuristic.texts)) if (mask >> q) & 1]
+        return [self._texts[q][0] for q in range(len(self._texts)) if (mask >> q) & 1]
 
     def _d_idx(self, secs):
         import torch
@@ -351,6 +352,11 @@ class TStarSearcher:
         cands, vframes, res = ctx
         vconf = res.cell_conf[:, 0].cpu().numpy()
         vmask = res.cell_mask[:, 0].cpu().numpy().astype(np.uint32)
+        self._verify_replay(cands, vconf, vmask, secs, names_per_frame, vframes, res, 0)
+
+    def _verify_replay(self, cands, vconf, vmask, secs, names_per_frame, vframes=None, res=None, res_offset=0):
+        """Sequential ``remaining_targets`` logic over already-scored candidate frames: candidate j of this
+        searcher is row ``j`` of vconf/vmask (and image ``res_offset + j`` of ``res`` / ``vframes``)."""
         slot = {i: j for j, i in enumerate(cands)}
         upd_s, upd_v = [], []
         for i, (sec, names) in enumerate(zip(secs, names_per_frame)):
@@ -363,9 +369,9 @@ class TStarSearcher:
                     upd_v.append(single_conf)
                     self.frames_scored += 1
                     self.detector_calls += 1
-                    if self.keep_visual_history:
-                        frame = vframes[j].cpu().numpy()
-                        det = self.heuristic._detections_from(res, j)
+                    if self.keep_visual_history and res is not None:
+                        frame = vframes[res_offset + j].cpu().numpy()
+                        det = self.heuristic._detections_from(res, res_offset + j)
                         self.image_grid_iters.append([frame])
                         self.detect_annotot_iters.append(self.heuristic.bbox_visualization([frame], [det]))
                         self.detect_bbox_iters.append([det])

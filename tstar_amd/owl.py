@@ -71,7 +71,7 @@ class OwlScorer:
         _lib.check(rc, "tstar_owl_create")
         self._h = h
         self.max_batch = int(max_batch)
-        self.Q = 0
+        self.Qs = {}                # query-set slot -> number of queries
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     @classmethod
@@ -93,46 +93,53 @@ class OwlScorer:
             pass
 
     # ---- queries
-    def set_queries(self, input_ids: np.ndarray, attention_mask: np.ndarray, class_weight: Sequence[float]):
+    @property
+    def Q(self) -> int:
+        return self.Qs.get(0, 0)
+
+    def set_queries(self, input_ids: np.ndarray, attention_mask: np.ndarray, class_weight: Sequence[float], slot: int = 0):
         ids = np.ascontiguousarray(input_ids, dtype=np.int32)
         am = np.ascontiguousarray(attention_mask, dtype=np.int32)
         w = np.ascontiguousarray(class_weight, dtype=np.float32)
         Q = ids.shape[0]
         if ids.shape != (Q, W.T_LEN) or am.shape != ids.shape or w.shape != (Q,):
             raise ValueError("set_queries: ids/mask must be [Q,16] and class_weight [Q]")
-        rc = self._lib.tstar_owl_set_queries(self._h, ids.ctypes.data, am.ctypes.data, w.ctypes.data, Q,
+        rc = self._lib.tstar_owl_set_queries(self._h, int(slot), ids.ctypes.data, am.ctypes.data, w.ctypes.data, Q,
                                              _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_set_queries")
-        self.Q = Q
+        self.Qs[int(slot)] = Q
 
-    def set_query_embeds(self, embeds: np.ndarray, query_mask: Sequence[int], class_weight: Sequence[float]):
+    def set_query_embeds(self, embeds: np.ndarray, query_mask: Sequence[int], class_weight: Sequence[float], slot: int = 0):
         e = np.ascontiguousarray(embeds, dtype=np.float32)
         m = np.ascontiguousarray(query_mask, dtype=np.uint8)
         w = np.ascontiguousarray(class_weight, dtype=np.float32)
         Q = e.shape[0]
         if e.shape != (Q, W.PROJ) or m.shape != (Q,) or w.shape != (Q,):
             raise ValueError("set_query_embeds: embeds [Q,512], mask [Q], class_weight [Q]")
-        rc = self._lib.tstar_owl_set_query_embeds(self._h, e.ctypes.data, m.ctypes.data, w.ctypes.data, Q,
+        rc = self._lib.tstar_owl_set_query_embeds(self._h, int(slot), e.ctypes.data, m.ctypes.data, w.ctypes.data, Q,
                                                   _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_set_query_embeds")
-        self.Q = Q
+        self.Qs[int(slot)] = Q
 
-    def set_class_weights(self, class_weight: Sequence[float]):
+    def set_class_weights(self, class_weight: Sequence[float], slot: int = 0):
         w = np.ascontiguousarray(class_weight, dtype=np.float32)
-        if w.shape != (self.Q,):
+        if w.shape != (self.Qs.get(int(slot), 0),):
             raise ValueError("set_class_weights: one weight per installed query")
-        rc = self._lib.tstar_owl_set_class_weights(self._h, w.ctypes.data, self.Q, _lib.stream_ptr())
+        rc = self._lib.tstar_owl_set_class_weights(self._h, int(slot), w.ctypes.data, len(w), _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_set_class_weights")
 
-    def get_query_embeds(self) -> np.ndarray:
-        out = np.empty((self.Q, W.PROJ), dtype=np.float32)
-        rc = self._lib.tstar_owl_get_query_embeds(self._h, out.ctypes.data, self.Q, _lib.stream_ptr())
+    def get_query_embeds(self, slot: int = 0) -> np.ndarray:
+        q = self.Qs.get(int(slot), 0)
+        out = np.empty((q, W.PROJ), dtype=np.float32)
+        rc = self._lib.tstar_owl_get_query_embeds(self._h, int(slot), out.ctypes.data, q, _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_get_query_embeds")
         return out
 
     # ---- scoring
-    def score(self, images, grid_rows: int, grid_cols: int, want_logits: bool = False) -> ScoreResult:
-        """images: torch u8 cuda tensor [B,H,W,3] (contiguous)."""
+    def score(self, images, grid_rows: int, grid_cols: int, want_logits: bool = False,
+              image_sets: Optional[Sequence[int]] = None) -> ScoreResult:
+        """images: torch u8 cuda tensor [B,H,W,3] (contiguous); ``image_sets``: query-set slot per image
+        (default: slot 0 for all)."""
         torch = self._torch
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3 or not images.is_cuda:
             raise ValueError("score: images must be a cuda uint8 tensor [B,H,W,3]")
@@ -148,12 +155,20 @@ class OwlScorer:
             cell_mask=torch.empty((B, ncell), dtype=torch.int32, device=dev),
             n_kept=torch.empty((B,), dtype=torch.int32, device=dev),
         )
+        sets = None
+        if image_sets is not None:
+            sets = np.ascontiguousarray(image_sets, dtype=np.int32)
+            if sets.shape != (B,):
+                raise ValueError("score: image_sets needs one slot per image")
         if want_logits:
-            r.logits = torch.empty((B, W.NPATCH, self.Q), dtype=torch.float32, device=dev)
+            qs = {self.Qs.get(int(v), 0) for v in (sets if sets is not None else [0])}
+            if len(qs) != 1:
+                raise ValueError("score: raw logits need the same query count for every image")
+            r.logits = torch.empty((B, W.NPATCH, qs.pop()), dtype=torch.float32, device=dev)
             r.boxes_cxcywh = torch.empty((B, W.NPATCH, 4), dtype=torch.float32, device=dev)
         rc = self._lib.tstar_owl_score(
             self._h, images.data_ptr(), B, H, Wd, grid_rows, grid_cols,
-            r.scores.data_ptr(), r.labels.data_ptr(), r.boxes.data_ptr(), r.cell_conf.data_ptr(),
+            None if sets is None else sets.ctypes.data, r.scores.data_ptr(), r.labels.data_ptr(), r.boxes.data_ptr(), r.cell_conf.data_ptr(),
             r.cell_mask.data_ptr(), r.n_kept.data_ptr(),
             _lib.ptr(r.logits), _lib.ptr(r.boxes_cxcywh), _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_score")
