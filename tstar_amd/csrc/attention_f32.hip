@@ -112,33 +112,38 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[c][e], s, 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
-            // masks + block max
-            const int key0 = kb * KB + 4 * h;
+            // masks (only the last key block of the full-attention mode can hold invalid keys) + block max
             float mb = -INFINITY;
+            if (MODE == 1 || kb == nkb - 1) {
+                const int key0 = kb * KB + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2);
-                bool ok = key < T;
-                if (MODE == 1) ok = ok && key <= q && key_mask[(size_t)b * T + (key < T ? key : 0)] != 0;
-                s[r] = ok ? s[r] : -INFINITY;
-                mb = fmaxf(mb, s[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2);
+                    bool ok = key < T;
+                    if (MODE == 1) ok = ok && key <= q && key_mask[(size_t)b * T + (key < T ? key : 0)] != 0;
+                    s[r] = ok ? s[r] : -INFINITY;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mb = fmaxf(mb, s[r]);
             mb = fmaxf(mb, __shfl_xor(mb, 32));
             const float m_new = fmaxf(m_run, mb);
             // m_new is finite as soon as one key of this or an earlier block is valid
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = exp2f(m_run - m_use);     // exp2(-inf) = 0 on the first block
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);     // exp2(-inf) = 0 on the first block
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(s[r] - m_use);
+                s[r] = __builtin_amdgcn_exp2f(s[r] - m_use);
                 ps += s[r];
             }
             ps += __shfl_xor(ps, 32);
             l_run = l_run * alpha + ps;
             m_run = m_new;
+            if (!__all(alpha == 1.0f)) {                  // running maxima settle after a few blocks: skip the rescale
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
             // O^T[d][q] += sum_key V[key][d] * P[q][key]
             const float* vp = &Vs[cur][4 * h][l31];
             __builtin_amdgcn_s_setprio(1);
