@@ -123,6 +123,10 @@ def cpu_baseline(args, stats):
 
 def main():
     args = parse()
+    # the searcher prints progress like the reference ("Found target ...", sampler warnings): keep stdout
+    # clean for the ONE JSON line
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,7 +282,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, {"grid_calls": grid_calls / args.steps,
                                                       "verify_calls": verify_calls / args.steps})
             out["config"]["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
