@@ -143,6 +143,8 @@ class OwlScorer:
         torch = self._torch
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3 or not images.is_cuda:
             raise ValueError("score: images must be a cuda uint8 tensor [B,H,W,3]")
+        if grid_rows < 1 or grid_cols < 1:
+            raise ValueError("score: the grid must be at least 1x1")
         images = images.contiguous()
         B, H, Wd, _ = images.shape
         dev = images.device
