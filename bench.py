@@ -209,6 +209,14 @@ def main():
     # (kernel attributes, resample tables, workspace growth) at its own batch sizes
     n_warm = 0 if args.warmup <= 0 else max(args.warmup, min(args.lockstep, 15) * conc)
     run_many([10_000 + rank * 1000 + w for w in range(n_warm)])
+    # latency of ONE search running alone (the "sec/video to 8 keyframes" half of the metric, untimed):
+    solo_latency = None
+    if n_warm > 0:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_group(heuristics[0], store, g, [20_000 + rank], args.search_nframes)
+        torch.cuda.synchronize()
+        solo_latency = time.perf_counter() - t1
     barrier()
     # time every 5th GEMM / attention launch with HIP event pairs (5 is co-prime with the 4-GEMM layer
     # pattern and the 52-GEMM forward, so every shape is sampled evenly); timing all of them costs 2.2 %
@@ -271,7 +279,7 @@ def main():
                             f"(targets {TARGETS}, cues {CUES}), OWL-ViT-B/32 {args.weights} weights (seeded synthetic), grid {g}x{g} = "
                             f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
                 "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc, "lockstep_items_per_batch": max(1, min(args.lockstep, 15)),
-                "mean_search_latency_sec": latency,
+                "mean_search_latency_sec": latency, "single_search_alone_latency_sec": solo_latency,
                 "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,
                 "detector_images_per_video": images / args.steps, "max_batch": args.max_batch,
                 "keyframes_rank0_step0": keys[0], "gathered_keyframe_rows": len(all_keys),

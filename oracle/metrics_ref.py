@@ -3,7 +3,7 @@
 torch restatement of the reference's search-quality metrics
 (/root/reference/LVHaystackBench/val_tstar_results.py:48-95 SSIM, :186-256 P/R/F1 and ANND).
 PINNED by tests/golden/g10_metrics.npz, produced by importing the reference module itself
-(tools/make_goldens.py, stubs for its absent cv2 / skimage imports).
+(tests/golden/make_goldens.py, stubs for its absent cv2 / skimage imports).
 """
 from __future__ import annotations
 

@@ -8,7 +8,8 @@ mmengine, mmdet) are replaced by stub modules whose semantics are stated here:
   supervision.Detections.from_transformers = plain container of boxes / scores / labels
 No reference source is copied: only inputs and outputs are written.
 
-    python tools/make_goldens.py            (takes a few minutes on 8 cores)
+    python tests/golden/make_goldens.py            (takes about 7 minutes on 8 cores)
+    python tests/golden/make_goldens.py --only-g10
 """
 import os
 import sys
@@ -17,7 +18,7 @@ import types
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 REF = "/root/reference"

@@ -1,4 +1,4 @@
-"""Helpers shared by tools/make_goldens.py (runs the REFERENCE, in the build container only) and
+"""Helpers shared by tests/golden/make_goldens.py (runs the REFERENCE, in the build container only) and
 the parity tests (run the oracle / the HIP path against the committed vectors)."""
 import hashlib
 

@@ -262,7 +262,7 @@ def test_errors():
 
 
 # ------------------------------------------------------------------------------------------------
-# Goldens produced by the REFERENCE (tools/make_goldens.py) replayed through the HIP product.
+# Goldens produced by the REFERENCE (tests/golden/make_goldens.py) replayed through the HIP product.
 import os
 
 import golden_util as GU

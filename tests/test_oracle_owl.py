@@ -1,5 +1,5 @@
 """CPU: detector / preprocess oracle against goldens produced by the reference's OWLInterface running
-HF transformers (tools/make_goldens.py), and directly against PIL / HF where importable."""
+HF transformers (tests/golden/make_goldens.py), and directly against PIL / HF where importable."""
 import os
 
 import numpy as np
