@@ -16,7 +16,7 @@ lives in the un-vendored third-party package ``transformers`` (reference pin
 
 Pinned by: tests/test_oracle_owl.py (bit/1e-5 comparison with the installed HF
 ``OwlViTForObjectDetection`` when transformers is importable) and the golden
-vectors tests/golden/g7_*.npz produced from HF by tools/make_goldens_owl.py.
+vectors tests/golden/g7_*.npz produced from HF by tests/golden/make_goldens.py.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import this module.  Plain torch fp32 ops; weights come in as the dict
