@@ -10,8 +10,8 @@ numpy restatement of the byte arithmetic in front of the detector:
   algorithm is Pillow's src/libImaging/Resample.c (precompute_coeffs,
   normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc/Vertical_8bpc):
   horizontal pass first, uint8 intermediate, 22-bit fixed-point coefficients.
-  PINNED: tests/test_oracle_resize.py compares with PIL bit for bit, and
-  tests/golden/g8_*.npz hold PIL/HF outputs.
+  PINNED: tests/test_oracle_owl.py::test_bicubic_equals_pillow compares with PIL bit for bit, and
+  tests/golden/g7_g8_detector.npz holds hashes / crops of the HF processor output.
 * ``hf_rescale_normalize`` -- HF image_transforms.py:118-122 and :419-437.
 * ``cv_bilinear_resize`` -- INTER_LINEAR 8-bit resize in the fixed-point form of
   OpenCV's generic C++ path (HResizeLinear / VResizeLinear<uchar,int,short>,
