@@ -36,8 +36,9 @@ constexpr int BK = 32, LDS_LD = BK + 4;
 
 __device__ __forceinline__ float epi_act(float v, int act) {
     // quick_gelu(v) = v * sigmoid(1.702 v); exp through the raw v_exp_f32 (2^x, ~1 ulp): the epilogue runs
-    // while the matrix pipe idles, so its VALU cost is on the critical path of short-K launches
-    if (act == ACT_QGELU) return v / (1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896340736f * v));
+    // and the reciprocal through v_rcp_f32 (1 ulp): the epilogue runs while the matrix pipe idles, so its VALU
+    // cost is on the critical path of short-K launches
+    if (act == ACT_QGELU) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896340736f * v));
     if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     return v;
 }
