@@ -92,3 +92,28 @@ def test_ingest_rejects_bad_arguments():
     assert lib.tstar_frames_to_grid(d.data_ptr(), 1, 1, 4, i.data_ptr(), 1, 1, d.data_ptr(), 0, None) == 1
     assert lib.tstar_frames_resize(d.data_ptr(), 1, 3, 4, i.data_ptr(), 1, 2, 2, d.data_ptr(), 1, None) == 1   # odd H, NV12
     assert lib.tstar_frames_to_grid(None, 1, 2, 2, i.data_ptr(), 1, 1, d.data_ptr(), 0, None) == 1
+
+
+def test_odd_resolution_and_non_unit_fps_store():
+    """Arbitrary frame sizes (240x427) and a 29.97 fps stream: N = int(total / raw_fps), grid bit-exact."""
+    from oracle import resize_ref as R
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import FrameStore
+    L, lib = _lib()
+    rs = np.random.RandomState(5)
+    raw_fps, raw_total = 29.97, 1200                       # 40.04 s -> 40 logical seconds
+    frames = rs.randint(0, 256, (40, 240, 427, 3), dtype=np.uint8)
+    st = FrameStore(torch.from_numpy(frames).cuda(), raw_fps, raw_total)
+    h = OWLInterface(synthetic_seed=0, max_batch=4)
+    s = TStarSearcher(st, h, ["couch"], [], search_nframes=4, image_grid_shape=(2, 2), search_budget=0.5,
+                      confidence_threshold=0.6, rng=np.random.RandomState(0), keep_visual_history=True)
+    assert s.total_frame_num == int(raw_total / raw_fps * 1) == 40 and abs(s.duration - raw_total / raw_fps) < 1e-12
+    assert s.search_budget == min(1000, 40 * 0.5)
+    fr, ts = s.search()
+    assert fr.shape == (4, 240, 427, 3) and s.iterations == 5          # budget 20 -> 5 iterations of 4
+    secs0 = [0, 10, 20, 30]
+    assert np.array_equal(s.image_grid_iters[0][0].shape, (190, 400, 3))
+    grid = s._device_grid(secs0).cpu().numpy()
+    assert np.array_equal(grid, R.frames_to_grid([frames[i] for i in secs0], 2, 2))
+    assert np.array_equal(fr, frames[[int(t) for t in ts]])
