@@ -38,7 +38,7 @@ extern "C" {
 #define TSTAR_OWL_QDIM 512
 #define TSTAR_OWL_TEXT_LEN 16
 #define TSTAR_OWL_MAX_QUERIES 32
-#define TSTAR_OWL_MAX_SETS 16      /* independent query sets (questions) resident at once */
+#define TSTAR_OWL_MAX_SETS 32      /* independent query sets (questions) resident at once */
 
 const char* tstar_last_error(void);
 int tstar_abi_version(void);
@@ -57,20 +57,31 @@ typedef struct tstar_owl tstar_owl;
  * can install queries).  h_norm_lut: 3*256 float32, the rescale+normalise value of every
  * (channel, u8) pair, computed by the host with the reference's arithmetic
  * (HF image_transforms.py rescale/normalize via image_processing_pil_owlvit.py).
- * weights_bf16 != 0 (BASELINE config 5, "bf16 ViT weights"): every GEMM weight matrix is also kept
- * as bfloat16 (round to nearest even; exact if the blob already holds bf16 values) and the GEMMs run
- * on the bf16 matrix pipe with the float32 activations split exactly into three bf16 terms -- an
- * f32-accumulated product of f32 activations and bf16 weights. */
+ * weights_mode:
+ *   TSTAR_WEIGHTS_F32 (0): float32 weights, exact-f32 MFMA (v_mfma_f32_32x32x2_f32) -- the reference's
+ *     arithmetic and the mode every headline number is quoted in.
+ *   TSTAR_WEIGHTS_BF16 (1) (BASELINE config 5, "bf16 ViT weights"): every GEMM weight matrix is also kept
+ *     as bfloat16 (round to nearest even; exact if the blob already holds bf16 values) and the GEMMs run
+ *     on the bf16 matrix pipe with the float32 activations split exactly into three bf16 terms -- an
+ *     f32-accumulated product of f32 activations and bf16 weights.
+ *   TSTAR_WEIGHTS_F32_SPLIT (2): float32 checkpoints on the bf16 matrix pipe: each weight is kept as two
+ *     bfloat16 terms hi + lo and each activation is split into two terms on the fly (round to nearest,
+ *     16 significand bits per operand); C += a_lo*w_hi + a_hi*w_lo + a_hi*w_hi with exact products and f32
+ *     accumulation (the 2^-18 a_lo*w_lo term is dropped).  Detector scores stay within 1e-3 of the
+ *     float32 path (tests state the measured bound); opt-in, never the default. */
+#define TSTAR_WEIGHTS_F32 0
+#define TSTAR_WEIGHTS_BF16 1
+#define TSTAR_WEIGHTS_F32_SPLIT 2
 int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision,
                      const float* h_text_blob, size_t n_text, const float* h_norm_lut, int max_batch,
-                     int weights_bf16);
+                     int weights_mode);
 int tstar_owl_destroy(tstar_owl* h);
 
 /* Replaces the text half of processor(...)+model(...) that the reference recomputes on every
  * detector call (interface_heuristic.py:234,239 -> HF modeling_owlvit.py:945-958, 631-663):
  * runs the CLIP text tower once for Q queries (ids/mask int32 [Q,16]) and keeps the
  * L2-normalised query embeddings resident.  h_class_weight [Q] = object2weight of each
- * query's name (interface_searcher.py:88-91,136).  `query_set` (0..15) is the slot the queries are stored
+ * query's name (interface_searcher.py:88-91,136).  `query_set` (0..TSTAR_OWL_MAX_SETS-1) is the slot the queries are stored
  * in: several (video, question) items can be resident at once and every image of a tstar_owl_score call
  * names the slot it is scored against (the reference keeps exactly one query set, = slot 0).
  * Synchronises `stream`. */
@@ -190,6 +201,9 @@ int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const flo
 /* bf16-weight GEMM (diagnostic): W is rounded to bfloat16 on the device, A is split exactly; synchronises */
 int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                      int M, int N, int K, int act, int tile_cfg, void* stream);
+/* f32-split GEMM (diagnostic): W is split into two bfloat16 terms on the device, A into two on the fly; synchronises */
+int tstar_gemm_f32_split(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
+                         int M, int N, int K, int act, int tile_cfg, void* stream);
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream);
 /* qkv [B*T, 3*heads*64] -> out [B*T, heads*64]; mode 0 full, 1 causal + key mask u8 [B,T] */
 int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode,

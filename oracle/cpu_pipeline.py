@@ -39,10 +39,24 @@ class CpuOwlDetector:
                 self._qe = owl_ref.text_query_embeds(self.ids, self.mask, self.wt).numpy()
         return self._qe
 
-    def inference_detector(self, image: np.ndarray):
+    @staticmethod
+    def preprocess(image: np.ndarray, library_speed: bool = False) -> np.ndarray:
+        """uint8 [H,W,3] -> float32 [3,768,768].  ``library_speed``: use Pillow's own BICUBIC resize when it is
+        importable (bit-identical to resize_ref.pil_bicubic_resize, tests/test_oracle_owl.py) -- for timing the
+        CPU baseline at the speed of the library the reference calls, not of its numpy restatement."""
+        if library_speed:
+            try:
+                from PIL import Image
+                u8 = np.asarray(Image.fromarray(image).resize((768, 768), Image.BICUBIC))
+                return resize_ref.hf_rescale_normalize(u8)
+            except ImportError:
+                pass
+        return resize_ref.owl_preprocess(image)
+
+    def inference_detector(self, image: np.ndarray, library_speed: bool = False):
         """One image (HxWx3 uint8) -> (xyxy f32 [n,4], class_id i64 [n], confidence f32 [n]), score > 0.005."""
         H, Wd = image.shape[:2]
-        px = resize_ref.owl_preprocess(image)[None]
+        px = self.preprocess(image, library_speed)[None]
         out = owl_ref.detect(px, self.query_embeds(), self.wv, H, Wd, query_mask=self.ids[:, 0] > 0)
         s, l, b = out["kept"][0]
         return b, l, s, out

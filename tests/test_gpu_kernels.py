@@ -97,6 +97,47 @@ def test_gemm_bf16_weights_exact_split(lib, cfg, M, N, K, act):
         assert (dC2.cpu() - want).abs().max().item() < 3e-5 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K,act", [(577, 768, 3072, 0), (130, 256, 64, 1), (1154, 512, 768, 2), (25388, 768, 768, 0)])
+def test_gemm_f32_split(lib, cfg, M, N, K, act):
+    """f32-split GEMM (weights_mode 2): both f32 operands carried as two round-to-nearest bf16 terms (16 significand
+    bits), three exact bf16 MFMA products per K step, f32 accumulation.  Error model: each operand is off by
+    <= 2^-18 relative (two 8-bit round-to-nearest terms) and the dropped lo*lo product is <= 2^-18 |a w|, so
+    |C - ref| <= 3 * 2^-18 * sum|a w| worst case; with random signs the relative rms is ~4e-6, about 4-5x the
+    exact-f32 tile's own accumulation rounding at K = 3072."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    A[::7] *= 1e-3                                             # wide dynamic range across rows
+    A[:, ::5] *= 37.0
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    ref = A.to(torch.float64) @ W.to(torch.float64).t() + b.to(torch.float64)
+    mag = A.abs().to(torch.float64) @ W.abs().to(torch.float64).t() + b.abs().to(torch.float64)
+    dA, dW, db = A.cuda(), W.cuda(), b.cuda()
+    dC = torch.full((M, N), float("nan"), device="cuda")
+    _check(lib.tstar_gemm_f32_split(dA.data_ptr(), dW.data_ptr(), dC.data_ptr(), db.data_ptr(), None, M, N, K, 0, cfg,
+                                    torch.cuda.current_stream().cuda_stream))
+    out = dC.cpu().to(torch.float64)
+    assert torch.isfinite(out).all()
+    err = ((out - ref).abs() / mag).max().item()
+    assert err < 3 * 2.0 ** -18, err                           # hard bound of the error model
+    # relative to the result itself: 2^-18 class, within an order of magnitude of the exact-f32 tile
+    dC32 = torch.empty((M, N), device="cuda")
+    _check(lib.tstar_gemm_f32(dA.data_ptr(), dW.data_ptr(), dC32.data_ptr(), db.data_ptr(), None, M, N, K, 0,
+                              torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    rms = ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    rms32 = ((dC32.cpu().to(torch.float64) - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rms < 8e-6 and rms < 40 * rms32 + 1e-7, (rms, rms32)
+    if act:
+        dC2 = torch.empty((M, N), device="cuda")
+        _check(lib.tstar_gemm_f32_split(dA.data_ptr(), dW.data_ptr(), dC2.data_ptr(), db.data_ptr(), None, M, N, K, act,
+                                        cfg, torch.cuda.current_stream().cuda_stream))
+        r32 = ref.to(torch.float32)
+        want = r32 * torch.sigmoid(1.702 * r32) if act == 1 else F.gelu(r32)
+        assert (dC2.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
 def test_gemm_asymmetric_identity(lib):
     """A = I against an asymmetric W: catches row/col swaps in the C/D layout."""
     N = K = 128

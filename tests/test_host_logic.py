@@ -119,3 +119,56 @@ def test_sharded_gather_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_spline_pool_matches_in_process_fit(monkeypatch):
+    """The lock-step host path fits each item's smoothing spline in a worker process: (t, c, k) must be
+    bit-identical to the in-process ``UnivariateSpline(x, y, s=0.5)`` the reference calls
+    (interface_searcher.py:265), in input order, for more problems than workers."""
+    from scipy.interpolate import UnivariateSpline
+    from tstar_amd import spline_pool
+    N = 600
+    x = np.arange(N, dtype=np.int32)
+    probs = []
+    for seed in range(5):
+        rs = np.random.RandomState(seed)
+        y = np.full(N, 0.1)
+        idx = rs.choice(N, 25, replace=False)
+        y[idx] = rs.rand(25)
+        probs.append((x, y))
+    pool = spline_pool.SplinePool(2)
+    try:
+        got = pool.fit_many(probs, s=0.5)
+    finally:
+        pool.close()
+    for (xx, yy), (t2, c2, k2) in zip(probs, got):
+        t, c, k = UnivariateSpline(xx, yy, s=0.5)._eval_args
+        assert k2 == k and np.array_equal(t2, t)
+        assert np.array_equal(c2[:len(c)], c) and not c2[len(c):].any()
+    # disabled pool -> in-process path, same answers
+    monkeypatch.setenv("TSTAR_SPLINE_WORKERS", "0")
+    monkeypatch.setattr(spline_pool, "_pool", None)
+    monkeypatch.setattr(spline_pool, "_pool_failed", False)
+    assert spline_pool.get_pool() is None
+    same = spline_pool.fit_many(probs[:2], s=0.5)
+    assert np.array_equal(same[0][0], got[0][0]) and np.array_equal(same[1][1], got[1][1][:len(same[1][1])])
+
+
+def test_spline_pool_reports_fit_errors(monkeypatch):
+    """A fit the library rejects (x not increasing) surfaces as an error, not as a hang or a wrong curve;
+    through the module-level entry the caller sees scipy's own exception."""
+    from tstar_amd import spline_pool
+    bad = (np.array([0.0, 2.0, 1.0, 3.0, 4.0]), np.zeros(5))
+    good = (np.arange(8.0), np.arange(8.0) ** 2)
+    pool = spline_pool.SplinePool(1)
+    with pytest.raises(spline_pool.SplinePoolError, match="ValueError"):
+        pool.fit_many([good, bad])
+    assert len(pool) == 0                              # closed after a failure
+    with pytest.raises(spline_pool.SplinePoolError, match="closed"):
+        pool.fit_many([good])
+    monkeypatch.setattr(spline_pool, "_pool", None)                # module state restored after the test
+    monkeypatch.setattr(spline_pool, "_pool_failed", False)
+    with pytest.raises(ValueError):
+        spline_pool.fit_many([bad, bad])
+    if spline_pool._pool is not None:
+        spline_pool._pool.close()

@@ -30,12 +30,18 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int* __res
     const int q = blockIdx.x;
     for (int d = threadIdx.x; d < D; d += blockDim.x) y[(size_t)q * D + d] = x[((size_t)q * T + eos[q]) * D + d];
 }
-// Wb[i] = bfloat16(W[i]), round to nearest even (exact when W already holds bf16 values)
-__global__ void f32_to_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ Wb, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) Wb[i] = (__bf16)W[i];
+// Wb[i] = bfloat16(W[i]), round to nearest even (exact when W already holds bf16 values);
+// optional second term Wlo[i] = bfloat16(W[i] - Wb[i]) (the difference is exact in f32)
+__global__ void f32_to_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ Wb, __bf16* __restrict__ Wlo, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float w = W[i];
+        const __bf16 hi = (__bf16)w;
+        Wb[i] = hi;
+        if (Wlo) Wlo[i] = (__bf16)(w - (float)hi);
+    }
 }
-int convert_f32_to_bf16(const float* W, __bf16* Wb, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, s, W, Wb, n);
+int convert_f32_to_bf16(const float* W, __bf16* Wb, __bf16* Wlo, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, s, W, Wb, Wlo, n);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
 }
@@ -77,13 +83,19 @@ struct tstar_owl {
     int *d_ids = nullptr, *d_eos = nullptr;
     uint8_t* d_kmask = nullptr;
     std::map<int, ResampleTable> tabs;   // in_size -> table to 768
-    // bf16-weight mode (BASELINE config 5): bfloat16 copy of every GEMM weight matrix
-    bool bf16w = false;
-    std::unordered_map<const float*, __bf16*> wb;
+    // weights_mode 1 (BASELINE config 5, bf16 weights): bfloat16 copy of every GEMM weight matrix;
+    // weights_mode 2 (f32 split): two bfloat16 terms hi + lo per matrix (16 significand bits)
+    int weights_mode = TSTAR_WEIGHTS_F32;
+    std::unordered_map<const float*, __bf16*> wb, wb_lo;
     const __bf16* bf16_of(const float* w) const {
-        if (!bf16w) return nullptr;
+        if (weights_mode == TSTAR_WEIGHTS_F32) return nullptr;
         auto it = wb.find(w);
         return it == wb.end() ? nullptr : it->second;
+    }
+    const __bf16* bf16_lo_of(const float* w) const {
+        if (weights_mode != TSTAR_WEIGHTS_F32_SPLIT) return nullptr;
+        auto it = wb_lo.find(w);
+        return it == wb_lo.end() ? nullptr : it->second;
     }
 };
 
@@ -141,7 +153,7 @@ static int get_table(tstar_owl* h, int in_size, ResampleTable** out, hipStream_t
 static GemmArgs mk_gemm(const tstar_owl* h, const float* A, const float* W, float* C, const float* bias, const float* res,
                         int M, int N, int K, int lda, int ldc, int act) {
     GemmArgs g{};
-    g.A = A; g.W = W; g.Wb = h ? h->bf16_of(W) : nullptr; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
+    g.A = A; g.W = W; g.Wb = h ? h->bf16_of(W) : nullptr; g.Wb2 = h ? h->bf16_lo_of(W) : nullptr; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0; g.tile_cfg = -1; g.m_split = 0;
     return g;
 }
@@ -188,7 +200,7 @@ int tstar_abi_version(void) { return 1; }
 size_t tstar_owl_vision_blob_floats(void) { return vision_floats(); }
 size_t tstar_owl_text_blob_floats(void) { return text_floats(); }
 
-static int make_bf16_copies(tstar_owl* h) {
+static int make_bf16_copies(tstar_owl* h, int mode) {
     std::vector<std::pair<const float*, size_t>> mats;
     mats.push_back({h->vw.patch_w, (size_t)V_D * V_PATCH_K});
     auto layer = [&](const LayerW& l, int d, int ff) {
@@ -204,21 +216,27 @@ static int make_bf16_copies(tstar_owl* h) {
         mats.push_back({h->tw.text_proj, (size_t)PROJ * T_D});
     }
     for (auto& m : mats) {
-        __bf16* p = nullptr;
+        __bf16 *p = nullptr, *lo = nullptr;
         TSTAR_HIP_CHECK(hipMalloc(&p, m.second * sizeof(__bf16)));
         h->wb[m.first] = p;
-        int rc = convert_f32_to_bf16(m.first, p, m.second, 0);
+        if (mode == TSTAR_WEIGHTS_F32_SPLIT) {
+            TSTAR_HIP_CHECK(hipMalloc(&lo, m.second * sizeof(__bf16)));
+            h->wb_lo[m.first] = lo;
+        }
+        int rc = convert_f32_to_bf16(m.first, p, lo, m.second, 0);
         if (rc) return rc;
     }
     TSTAR_HIP_CHECK(hipDeviceSynchronize());
-    h->bf16w = true;
+    h->weights_mode = mode;
     return TSTAR_OK;
 }
 
 int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision, const float* h_text_blob,
-                     size_t n_text, const float* h_norm_lut, int max_batch, int weights_bf16) {
+                     size_t n_text, const float* h_norm_lut, int max_batch, int weights_mode) {
     TSTAR_REQUIRE(out && h_vision_blob && h_norm_lut, "tstar_owl_create: null argument");
     TSTAR_REQUIRE(max_batch >= 1 && max_batch <= 1024, "tstar_owl_create: max_batch must be in 1..1024");
+    TSTAR_REQUIRE(weights_mode >= TSTAR_WEIGHTS_F32 && weights_mode <= TSTAR_WEIGHTS_F32_SPLIT,
+                  "tstar_owl_create: weights_mode must be 0 (f32), 1 (bf16) or 2 (f32 split)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         set_error("tstar_owl_create: no HIP device visible (this library has no CPU path)");
@@ -257,8 +275,8 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
         tstar_owl_destroy(h);
         return TSTAR_ERR_HIP;
     }
-    if (weights_bf16) {
-        rc = make_bf16_copies(h);
+    if (weights_mode != TSTAR_WEIGHTS_F32) {
+        rc = make_bf16_copies(h, weights_mode);
         if (rc) { tstar_owl_destroy(h); return rc; }
     }
     *out = h;
@@ -272,11 +290,12 @@ int tstar_owl_destroy(tstar_owl* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : h->tabs) free_table(&kv.second);
     for (auto& kv : h->wb) if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : h->wb_lo) if (kv.second) (void)hipFree(kv.second);
     delete h;
     return TSTAR_OK;
 }
 
-#define CHECK_SET(set, fn) TSTAR_REQUIRE((set) >= 0 && (set) < TSTAR_OWL_MAX_SETS, fn ": query_set must be in 0..15")
+#define CHECK_SET(set, fn) TSTAR_REQUIRE((set) >= 0 && (set) < TSTAR_OWL_MAX_SETS, fn ": query_set must be in 0..31")
 
 static int finish_queries(tstar_owl* h, int set, const uint8_t* h_mask, const float* h_w, int Q, hipStream_t s) {
     const size_t qo = (size_t)set * TSTAR_OWL_MAX_QUERIES;
@@ -470,23 +489,41 @@ int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const flo
     return gemm_f32(g, (hipStream_t)stream);
 }
 
-int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
-                     int N, int K, int act, int tile_cfg, void* stream) {
-    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_bf16w: null argument");
+static int gemm_converted(const char* fn, bool split, const float* d_A, const float* d_W, float* d_C, const float* d_bias,
+                          const float* d_residual, int M, int N, int K, int act, int tile_cfg, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    __bf16* wb = nullptr;
+    __bf16 *wb = nullptr, *lo = nullptr;
     TSTAR_HIP_CHECK(hipMalloc(&wb, (size_t)N * K * sizeof(__bf16)));
-    int rc = convert_f32_to_bf16(d_W, wb, (size_t)N * K, s);
+    if (split && hipMalloc(&lo, (size_t)N * K * sizeof(__bf16)) != hipSuccess) {
+        (void)hipFree(wb);
+        set_error(std::string(fn) + ": out of device memory");
+        return TSTAR_ERR_HIP;
+    }
+    int rc = convert_f32_to_bf16(d_W, wb, lo, (size_t)N * K, s);
     if (!rc) {
         GemmArgs g = mk_gemm(nullptr, d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
         g.Wb = wb;
+        g.Wb2 = lo;
         g.tile_cfg = tile_cfg;
         rc = gemm_f32(g, s);
     }
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(wb);
-    if (!rc && e != hipSuccess) { set_error(std::string("tstar_gemm_bf16w: ") + hipGetErrorString(e)); rc = TSTAR_ERR_HIP; }
+    if (lo) (void)hipFree(lo);
+    if (!rc && e != hipSuccess) { set_error(std::string(fn) + ": " + hipGetErrorString(e)); rc = TSTAR_ERR_HIP; }
     return rc;
+}
+
+int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
+                     int N, int K, int act, int tile_cfg, void* stream) {
+    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_bf16w: null argument");
+    return gemm_converted("tstar_gemm_bf16w", false, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
+}
+
+int tstar_gemm_f32_split(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
+                         int N, int K, int act, int tile_cfg, void* stream) {
+    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32_split: null argument");
+    return gemm_converted("tstar_gemm_f32_split", true, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
 }
 
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream) {

@@ -123,10 +123,35 @@ __device__ __forceinline__ void split4_bf16x3(const f32x4 v, u32x2 (&out)[3]) {
     }
 }
 
-template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+// Two-term round-to-nearest split for the SPLIT mode: hi = bf16(v), lo = bf16(v - hi); v - hi - lo is
+// below 2^-17 |v| and unbiased.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4_bf16x2(const f32x4 v, u32x2 (&out)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        f32x2 x; x[0] = v[2 * p]; x[1] = v[2 * p + 1];
+        const bf16x2 hi = __builtin_convertvector(x, bf16x2);
+        const unsigned hb = __builtin_bit_cast(unsigned, hi);
+        f32x2 r;
+        r[0] = x[0] - __uint_as_float(hb << 16);                      // exact
+        r[1] = x[1] - __uint_as_float(hb & 0xFFFF0000u);
+        const bf16x2 lo = __builtin_convertvector(r, bf16x2);
+        out[0][p] = hb;
+        out[1][p] = __builtin_bit_cast(unsigned, lo);
+    }
+}
+
+// WMODE 1: bf16 weights (Wb), activations split exactly into 3 terms.
+// WMODE 2: "f32 split" -- f32 weights pre-split into two bf16 arrays (Wb = hi, Wb2 = lo, round to
+//          nearest), activations split into 2 terms, C += a_lo*w_hi + a_hi*w_lo + a_hi*w_hi (the
+//          a_lo*w_lo term, 2^-18 relative, is dropped): 3 MFMAs per K = 16 like mode 1, operands
+//          carry 16 significand bits, products are exact, accumulation is f32.
+template <class CF, int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0, const int n0, float* smem_f) {
     constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM, BN = CF::BN;
-    constexpr int A_T = BM * 64, W_T = BN * 64, BUF = 3 * A_T + W_T;       // bytes
+    constexpr int NAT = WMODE == 2 ? 2 : 3, NWT = WMODE == 2 ? 2 : 1;     // operand terms
+    constexpr int A_T = BM * 64, W_T = BN * 64, BUF = NAT * A_T + NWT * W_T;       // bytes
     char* smem = reinterpret_cast<char*>(smem_f);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -136,7 +161,7 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
     const int c4 = t & 7, r0 = t >> 3;            // A: rows r0 + 32 i, float4 column c4
     const int wc = t & 3, wr = t >> 2;            // W: rows wr + 64 i, 16-B chunk wc
     const float* ap[NA];
-    const __bf16* bp[NB];
+    size_t bo[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         int ar = m0 + r0 + 32 * i;
@@ -144,7 +169,7 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
         ap[i] = g.A + (size_t)ar * g.lda + c4 * 4;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) bp[i] = g.Wb + (size_t)(n0 + wr + 64 * i) * g.K + wc * 8;
+    for (int i = 0; i < NB; ++i) bo[i] = (size_t)(n0 + wr + 64 * i) * g.K + wc * 8;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -155,25 +180,32 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[NA];
-    u32x4 rb[NB];
+    u32x4 rb[NWT][NB];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const u32x4*>(bp[i] + kt * BK);
+        for (int i = 0; i < NB; ++i) {
+            rb[0][i] = *reinterpret_cast<const u32x4*>(g.Wb + bo[i] + kt * BK);
+            if constexpr (NWT == 2) rb[NWT - 1][i] = *reinterpret_cast<const u32x4*>(g.Wb2 + bo[i] + kt * BK);
+        }
     };
     auto lstore = [&](int buf) {
         char* base = smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            u32x2 sp[3];
-            split4_bf16x3(ra[i], sp);
+            u32x2 sp[NAT];
+            if constexpr (WMODE == 2) split4_bf16x2(ra[i], sp);
+            else split4_bf16x3(ra[i], sp);
             const int off = bfw_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
+            for (int k = 0; k < NAT; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(base + 3 * A_T + bfw_off(wr + 64 * i, wc)) = rb[i];
+        for (int w = 0; w < NWT; ++w)
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                *reinterpret_cast<u32x4*>(base + NAT * A_T + w * W_T + bfw_off(wr + 64 * i, wc)) = rb[w][i];
     };
     gload(0);
     lstore(0);
@@ -188,22 +220,28 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                       // two K = 16 steps per tile
-            bf16x8 fa[3][TM], fw[TN];
+            bf16x8 fa[NAT][TM], fw[NWT][TN];
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < NAT; ++k)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     fa[k][i] = *reinterpret_cast<const bf16x8*>(base + k * A_T + bfw_off(wm * TM * 32 + i * 32 + l31, 2 * s + h));
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fw[j] = *reinterpret_cast<const bf16x8*>(base + 3 * A_T + bfw_off(wn * TN * 32 + j * 32 + l31, 2 * s + h));
+            for (int w = 0; w < NWT; ++w)
 #pragma unroll
-            for (int k = 2; k >= 0; --k)                    // smallest term first
+                for (int j = 0; j < TN; ++j)
+                    fw[w][j] = *reinterpret_cast<const bf16x8*>(base + NAT * A_T + w * W_T + bfw_off(wn * TN * 32 + j * 32 + l31, 2 * s + h));
+            // smallest term first: mode 1 a2*w, a1*w, a0*w; mode 2 a_lo*w_hi, a_hi*w_lo, a_hi*w_hi
+#pragma unroll
+            for (int p = 2; p >= 0; --p) {
+                const int ka = WMODE == 2 ? (p == 2 ? 1 : 0) : p;
+                const int kw = WMODE == 2 ? (p == 1 ? 1 : 0) : 0;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k][i], fw[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ka][i], fw[kw][j], acc[i][j], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         if (more) lstore(cur ^ 1);
@@ -304,40 +342,46 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int m0, const
     gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
 }
 
-template <class CF, bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <class CF, int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __global__ __launch_bounds__(256, CF::MINW) void gemm_f32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt = g.N / CF::BN;
     const int mt = (g.M + CF::BM - 1) / CF::BM;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
-    if (BF16W) gemm_tile_bf16w<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
+    if (WMODE) gemm_tile_bf16w<CF, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
     else gemm_tile<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
 }
 
 // Hybrid launch: rows [0, m_split) in 128x128 tiles (whole waves of the 512 resident slots), the
 // remaining rows in 64x128 tiles.  Blocks are dispatched in index order, so the half-size tiles
 // arrive last and fill the tail that a pure 128x128 grid leaves on most CUs.
-template <bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __global__ __launch_bounds__(256, 2) void gemm_f32_hybrid_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt = g.N / 128;
     const int n_big = (g.m_split / 128) * nt;
     if ((int)blockIdx.x < n_big) {
         const int tile = xcd_remap(blockIdx.x, n_big);
-        if (BF16W) gemm_tile_bf16w<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
+        if (WMODE) gemm_tile_bf16w<Cfg128, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
         else gemm_tile<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
     } else {
         const int n_small = gridDim.x - n_big;
         const int tile = xcd_remap(blockIdx.x - n_big, n_small);
-        if (BF16W) gemm_tile_bf16w<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        if (WMODE) gemm_tile_bf16w<Cfg64N, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
         else gemm_tile<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
     }
 }
 
-template <class CF, bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+// dynamic LDS of one block: double-buffered operand tiles
+template <int WMODE>
+constexpr int lds_bytes(int bm, int bn) {
+    return WMODE == 2 ? 2 * (2 * bm + 2 * bn) * 64 : WMODE == 1 ? 2 * (3 * bm + bn) * 64 : 2 * (bm + bn) * LDS_LD * 4;
+}
+
+template <class CF, int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
-    constexpr int lds = BF16W ? 2 * (3 * CF::BM + CF::BN) * 64 : 2 * (CF::BM + CF::BN) * LDS_LD * 4;
-    auto kern = gemm_f32_kernel<CF, BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>;
+    constexpr int lds = lds_bytes<WMODE>(CF::BM, CF::BN);
+    auto kern = gemm_f32_kernel<CF, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>;
     static bool attr_set = false;
     if (!attr_set) {
         TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -353,10 +397,10 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     return TSTAR_OK;
 }
 
-template <bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
-    constexpr int lds = BF16W ? 2 * (3 * 128 + 128) * 64 : 2 * (128 + 128) * LDS_LD * 4;
-    auto kern = gemm_f32_hybrid_kernel<BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>;
+    constexpr int lds = lds_bytes<WMODE>(128, 128);
+    auto kern = gemm_f32_hybrid_kernel<WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>;
     static bool attr_set = false;
     if (!attr_set) {
         TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -407,7 +451,7 @@ static int pick_cfg(int M, int N, int* m_split) {
     return best;
 }
 
-template <bool BF16W, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_mode(const GemmArgs& g, hipStream_t stream) {
     const int forced = g.tile_cfg;                           // -1 = auto
     int m_split = 0;
@@ -419,17 +463,18 @@ static int launch_mode(const GemmArgs& g, hipStream_t stream) {
     if (cfg == 3) {
         GemmArgs h = g;
         h.m_split = m_split;
-        return launch_hybrid<BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
+        return launch_hybrid<WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
     }
-    if (cfg == 0) return launch_cfg<Cfg128, BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
-    if (cfg == 1) return launch_cfg<Cfg64N, BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
-    return launch_cfg<Cfg64, BF16W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (cfg == 0) return launch_cfg<Cfg128, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (cfg == 1) return launch_cfg<Cfg64N, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    return launch_cfg<Cfg64, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
 }
 
 template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_one(const GemmArgs& g, hipStream_t stream) {
-    if (g.Wb) return launch_mode<true, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
-    return launch_mode<false, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (g.Wb && g.Wb2) return launch_mode<2, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (g.Wb) return launch_mode<1, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    return launch_mode<0, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
 }
 
 int gemm_f32(const GemmArgs& g, hipStream_t stream) {

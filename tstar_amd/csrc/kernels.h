@@ -10,6 +10,7 @@ struct GemmArgs {
     const float* A;      // [M, lda] row-major, K contiguous
     const float* W;      // [N, K] row-major (nn.Linear layout)
     const __bf16* Wb;    // optional bfloat16 copy of W: selects the bf16-weight tile (exact split of A)
+    const __bf16* Wb2;   // optional low term: W ~ Wb + Wb2 (both round-to-nearest) selects the f32-split tile
     float* C;            // [*, ldc]
     const float* bias;   // [N] or null
     const float* res;    // residual, same layout as C, or null (may alias C)
@@ -22,8 +23,9 @@ struct GemmArgs {
 };
 int gemm_f32(const GemmArgs& g, hipStream_t stream);
 
-// Wb[i] = bfloat16(W[i]) (round to nearest even); n elements
-int convert_f32_to_bf16(const float* W, __bf16* Wb, size_t n, hipStream_t s);
+// Wb[i] = bfloat16(W[i]) (round to nearest even); n elements.  With Wlo != null also
+// Wlo[i] = bfloat16(W[i] - Wb[i]) (the two-term split of the f32-split mode).
+int convert_f32_to_bf16(const float* W, __bf16* Wb, __bf16* Wlo, size_t n, hipStream_t s);
 
 // y[r,:] = LayerNorm(x[r,:]) * w + b over D (eps 1e-5, biased variance); D % 256 == 0, D <= 1024
 int layernorm_f32(const float* x, float* y, const float* w, const float* b, int rows, int D, hipStream_t s);

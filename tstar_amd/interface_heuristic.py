@@ -85,14 +85,14 @@ class OWLInterface(HeuristicInterface):
                     "for seeded synthetic OWL-ViT-B/32 weights or state_dict=<HF state dict>")
         else:
             self.weights_source = "state_dict"
-        if weights_dtype not in ("f32", "bf16"):
-            raise ValueError("weights_dtype must be 'f32' or 'bf16'")
+        if weights_dtype not in ("f32", "bf16", "f32_split"):
+            raise ValueError("weights_dtype must be 'f32', 'bf16' or 'f32_split'")
         if weights_dtype == "bf16":
             state_dict = W.round_weights_to_bf16(state_dict)
         self.weights_dtype = weights_dtype
         self.model_name_or_path = model_name_or_path
         self.scorer = OwlScorer(W.pack_blob(state_dict, W.vision_spec()), W.pack_blob(state_dict, W.text_spec()),
-                                max_batch=max_batch, weights_bf16=(weights_dtype == "bf16"))
+                                max_batch=max_batch, weights_mode=weights_dtype)
         self.device = device
         self.texts = ["couch", "table", "woman"]      # as the reference leaves it before reparameterisation (:203)
         self.detections_inbatch: List[Detections] = []
@@ -142,11 +142,11 @@ class OWLInterface(HeuristicInterface):
 
     def install_queries(self, slot: int, target_objects: List[str], cue_objects: List[str],
                         object2weight: Optional[Dict[str, float]] = None) -> List[List[str]]:
-        """Install a question's queries in slot 1..15 WITHOUT touching ``self.texts`` (slot 0 is what
+        """Install a question's queries in slot 1..31 WITHOUT touching ``self.texts`` (slot 0 is what
         ``reparameterize_object_list`` manages).  Several (video, question) items can then be scored in
         one batch, each image against its own slot.  Returns the texts list of the slot."""
-        if not 1 <= int(slot) <= 15:
-            raise ValueError("install_queries: slot must be in 1..15")
+        if not 1 <= int(slot) <= 31:
+            raise ValueError("install_queries: slot must be in 1..31")
         texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
         ids, am = encode_queries(texts, self.model_name_or_path)
         o2w = dict(object2weight or {})

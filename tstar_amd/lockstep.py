@@ -6,7 +6,8 @@ item contributes its grid image to ONE detector batch and its verification frame
 batch (each image scored against its own question's query set), while every item keeps its own
 sampler stream, device state and sequential ``remaining_targets`` logic.  Results are bit-identical to
 running the items one by one with the same per-item RNGs; the GPU sees larger GEMMs (M = sum of the
-items' images x 577), fewer launches and fewer synchronisation points per item.
+items' images x 577), fewer launches and fewer synchronisation points per item, and the items' host-side
+FITPACK fits run side by side in worker processes (tstar_amd.spline_pool).
 """
 from __future__ import annotations
 
@@ -14,7 +15,10 @@ from typing import List, Sequence, Tuple
 
 import numpy as np
 
+from . import spline_pool
 from .interface_searcher import TStarSearcher
+
+MAX_GROUP = 31          # TSTAR_OWL_MAX_SETS - 1 query-set slots (include/tstar_hip.h)
 
 
 def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray, list]]:
@@ -22,13 +26,12 @@ def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray
 
     All searchers must share one tstar_amd ``OWLInterface`` (fast path), use the same grid shape and
     carry their own ``rng`` (with the process-global numpy generator the draw order would depend on the
-    interleaving, unlike sequential runs).  At most 15 items at a time (query-set slots 1..15)."""
+    interleaving, unlike sequential runs).  At most 31 items at a time (query-set slots 1..31; slot 0 stays the heuristic's own)."""
     import torch
-    from scipy.interpolate import UnivariateSpline
     if not searchers:
         return []
-    if len(searchers) > 15:
-        raise ValueError("search_lockstep: at most 15 items per lock-step group")
+    if len(searchers) > MAX_GROUP:
+        raise ValueError(f"search_lockstep: at most {MAX_GROUP} items per lock-step group")
     h = searchers[0].heuristic
     shape = tuple(searchers[0].image_grid_shape)
     for s in searchers:
@@ -80,9 +83,9 @@ def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray
                                  for i, s in enumerate(act) if cand_l[i]])
             sets = [s._slot for i, s in enumerate(act) for _ in cand_l[i]]
             vres = h.score_batch(vframes, 1, 1, image_sets=sets)
-        # ... while the host fits the smoothing splines (FITPACK, as interface_searcher.py:265)
-        for i, s in enumerate(act):
-            t, c, k = UnivariateSpline(fits[i][0], fits[i][1], s=0.5)._eval_args
+        # ... while the host fits the smoothing splines (FITPACK, as interface_searcher.py:265): one worker
+        # process per item (tstar_amd.spline_pool), same scipy call, bit-identical coefficients
+        for s, (t, c, k) in zip(act, spline_pool.fit_many(fits, s=0.5)):
             s._state.set_spline(t, c, k)
         for s in act:
             s.store_score_distribution()

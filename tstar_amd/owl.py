@@ -51,12 +51,16 @@ class ScoreResult:
 class OwlScorer:
     """One OWL-ViT-B/32 scorer resident on the current HIP device."""
 
+    WEIGHTS_MODES = {"f32": 0, "bf16": 1, "f32_split": 2}      # TSTAR_WEIGHTS_* of include/tstar_hip.h
+
     def __init__(self, vision_blob: np.ndarray, text_blob: Optional[np.ndarray] = None, max_batch: int = 32,
-                 weights_bf16: bool = False):
+                 weights_mode: str = "f32"):
         import torch
         if not torch.cuda.is_available():
             raise _lib.TStarHipError("OwlScorer needs a HIP device (torch.cuda.is_available() is False); "
                                      "tstar_amd has no CPU path")
+        if weights_mode not in self.WEIGHTS_MODES:
+            raise ValueError("weights_mode must be one of " + ", ".join(repr(k) for k in self.WEIGHTS_MODES))
         self._torch = torch
         self._lib = _lib.load()
         vision_blob = np.ascontiguousarray(vision_blob, dtype=np.float32)
@@ -67,7 +71,7 @@ class OwlScorer:
         rc = self._lib.tstar_owl_create(
             C.byref(h), vision_blob.ctypes.data, vision_blob.size,
             None if text_blob is None else text_blob.ctypes.data, 0 if text_blob is None else text_blob.size,
-            lut.ctypes.data, int(max_batch), int(bool(weights_bf16)))
+            lut.ctypes.data, int(max_batch), self.WEIGHTS_MODES[weights_mode])
         _lib.check(rc, "tstar_owl_create")
         self._h = h
         self.max_batch = int(max_batch)

@@ -1,0 +1,151 @@
+"""Process pool for the host-side FITPACK fits of several searches advancing in lock-step.
+
+``update_frame_distribution`` fits ``UnivariateSpline(frames, scores, s=0.5)`` once per search iteration
+(/root/reference/TStar/interface_searcher.py:265).  The fit is sequential Fortran that holds the GIL and,
+with the reference's default 4x4 grid (63 iterations per video), costs ~15-20 ms per call on 3600 frames --
+more host time than the GPU needs for the iteration's detector work.  Within one search it overlaps with the
+verification batch; across the items of a lock-step group (tstar_amd.lockstep) the fits are independent, so
+they run here in worker processes, one item per worker, through the same scipy (bit-identical results).
+
+Workers are plain ``python spline_worker.py`` subprocesses (numpy + scipy only, no GPU runtime, no fork of the
+HIP-initialised parent) talking over pipes; they exit when the parent's pipe closes.
+"""
+from __future__ import annotations
+
+import atexit
+import os
+import struct
+import subprocess
+import sys
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "spline_worker.py")
+
+
+class SplinePoolError(RuntimeError):
+    pass
+
+
+def default_workers() -> int:
+    """TSTAR_SPLINE_WORKERS, else up to 16 workers out of half this rank's share of the host threads."""
+    env = os.environ.get("TSTAR_SPLINE_WORKERS")
+    if env is not None:
+        return max(0, int(env))
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    return max(1, min(16, (os.cpu_count() or 2) // (2 * ranks)))
+
+
+class SplinePool:
+    def __init__(self, workers: int):
+        if workers < 1:
+            raise ValueError("SplinePool needs at least one worker")
+        self._procs: List[subprocess.Popen] = []
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        try:
+            for _ in range(workers):
+                self._procs.append(subprocess.Popen([sys.executable, _WORKER], stdin=subprocess.PIPE,
+                                                    stdout=subprocess.PIPE, env=env))
+        except OSError as e:
+            self.close()
+            raise SplinePoolError(f"cannot start spline workers: {e}") from e
+        atexit.register(self.close)
+
+    def __len__(self):
+        return len(self._procs)
+
+    def close(self):
+        for p in self._procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self._procs:
+            try:
+                p.wait(timeout=2)
+            except Exception:
+                p.kill()
+        self._procs = []
+
+    @staticmethod
+    def _send(p: subprocess.Popen, x: np.ndarray, y: np.ndarray, s: float):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if x.shape != y.shape or x.ndim != 1:
+            raise ValueError("spline fit needs two 1-D arrays of equal length")
+        p.stdin.write(struct.pack("<qd", len(x), float(s)) + x.tobytes() + y.tobytes())
+        p.stdin.flush()
+
+    @staticmethod
+    def _recv(p: subprocess.Popen) -> Tuple[np.ndarray, np.ndarray, int]:
+        hdr = p.stdout.read(24)
+        if len(hdr) != 24:
+            raise SplinePoolError("spline worker exited")
+        status, n, k = struct.unpack("<qqq", hdr)
+        if status != 0:
+            raise SplinePoolError("spline worker: " + p.stdout.read(n).decode(errors="replace"))
+        buf = p.stdout.read(16 * n)
+        if len(buf) != 16 * n:
+            raise SplinePoolError("spline worker exited mid-reply")
+        t = np.frombuffer(buf, dtype=np.float64, count=n).copy()
+        c = np.frombuffer(buf, dtype=np.float64, count=n, offset=8 * n).copy()
+        return t, c, int(k)
+
+    def fit_many(self, problems: Sequence[Tuple[np.ndarray, np.ndarray]], s: float = 0.5):
+        """[(x, y)] -> [(t, c, k)] with c zero-padded to len(t) (FITPACK's own layout), input order."""
+        if not self._procs:
+            raise SplinePoolError("spline pool is closed")
+        out: List[Optional[Tuple[np.ndarray, np.ndarray, int]]] = [None] * len(problems)
+        w = len(self._procs)
+        try:
+            for lo in range(0, len(problems), w):
+                chunk = problems[lo:lo + w]
+                for p, (x, y) in zip(self._procs, chunk):
+                    self._send(p, x, y, s)
+                for j, p in enumerate(self._procs[:len(chunk)]):
+                    out[lo + j] = self._recv(p)
+        except (OSError, SplinePoolError):
+            self.close()                    # a half-served pool cannot be resynchronised
+            raise
+        return out
+
+
+_pool: Optional[SplinePool] = None
+_pool_failed = False
+
+
+def get_pool() -> Optional[SplinePool]:
+    """The process-wide pool (created on first use), or None when disabled (TSTAR_SPLINE_WORKERS=0) or
+    when the workers could not be started (the caller then fits in-process with the same scipy call)."""
+    global _pool, _pool_failed
+    if _pool is not None and len(_pool) > 0:
+        return _pool
+    if _pool_failed:
+        return None
+    n = default_workers()
+    if n == 0:
+        return None
+    try:
+        _pool = SplinePool(n)
+    except SplinePoolError as e:
+        _pool_failed = True
+        print(f"tstar_amd: {e}; fitting splines in-process", file=sys.stderr)
+        return None
+    return _pool
+
+
+def fit_many(problems: Sequence[Tuple[np.ndarray, np.ndarray]], s: float = 0.5):
+    """Fit every (x, y) with ``UnivariateSpline(x, y, s=s)``: in the worker pool when there is more than one
+    problem and a pool is available, otherwise in-process.  Returns [(t, c, k)] in input order."""
+    global _pool_failed
+    if len(problems) > 1:
+        pool = get_pool()
+        if pool is not None:
+            try:
+                return pool.fit_many(problems, s)
+            except (OSError, SplinePoolError) as e:
+                _pool_failed = True
+                print(f"tstar_amd: spline pool failed ({e}); fitting in-process", file=sys.stderr)
+    from scipy.interpolate import UnivariateSpline
+    return [UnivariateSpline(x, y, s=s)._eval_args for x, y in problems]
