@@ -172,3 +172,35 @@ def test_spline_pool_reports_fit_errors(monkeypatch):
         spline_pool.fit_many([bad, bad])
     if spline_pool._pool is not None:
         spline_pool._pool.close()
+
+
+def test_checkpoint_directory_round_trip(tmp_path):
+    """An HF ``save_pretrained`` directory (model.safetensors, HF parameter names, no box_bias buffer, extra
+    keys such as logit_scale) is found and packs into the C-ABI blobs exactly like the in-memory state dict --
+    the path a real ``google/owlvit-base-patch32`` download takes (interface_heuristic.py:207-210)."""
+    transformers = pytest.importorskip("transformers")
+    pytest.importorskip("safetensors")
+    import torch
+    from tstar_amd import weights as W
+    torch.manual_seed(0)
+    m = transformers.OwlViTForObjectDetection(transformers.OwlViTConfig())
+    d = tmp_path / "owlvit-base-patch32"
+    m.save_pretrained(str(d), safe_serialization=True)
+    ckpt = W.find_pretrained(str(d))
+    assert ckpt is not None and ckpt.endswith("model.safetensors")
+    sd = W.load_safetensors_state_dict(ckpt)
+    assert "box_bias" not in sd                                     # a non-persistent buffer: recomputed
+    vb = W.pack_blob(sd, W.vision_spec())
+    tb = W.pack_blob(sd, W.text_spec())
+    assert vb.size == W.spec_size(W.vision_spec()) and tb.size == W.spec_size(W.text_spec())
+    wv = W.unpack_blob(vb, W.vision_spec())
+    wt = W.unpack_blob(tb, W.text_spec())
+    ref = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    l0 = "owlvit.vision_model.encoder.layers.0."
+    qkv = np.concatenate([ref[l0 + f"self_attn.{n}_proj.weight"] for n in "qkv"])
+    assert np.array_equal(wv[l0 + "qkv_w"], qkv)
+    assert np.array_equal(wv["patch_w"].reshape(768, 3, 32, 32), ref["owlvit.vision_model.embeddings.patch_embedding.weight"])
+    assert np.array_equal(wv["cls_w"], ref["class_head.dense0.weight"])
+    assert np.array_equal(wt["text_proj"], ref["owlvit.text_projection.weight"])
+    assert np.array_equal(wv["box_bias"], m.box_bias.numpy())       # restated buffer == HF's
+    assert W.find_pretrained(str(tmp_path / "missing")) is None

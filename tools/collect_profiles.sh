@@ -1,0 +1,51 @@
+#!/bin/bash
+# Collect the round's measured evidence on an MI355X box (run through gpurun from the repo root):
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r01'
+# Writes summaries under gpurun_out/profiles_<tag>/ (the raw rocpd databases stay on the box); copy the
+# files to profiles/ afterwards.  Counter passes are separate runs with --kernel-trace only.
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+PY="python $ROOT/bench.py"
+
+# 1. the bench line itself (default flags) and the secondary workloads
+$PY --steps 8 --warmup 1 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
+$PY --steps 16 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights f32_split --no-cpu-baseline > "$OUT/${TAG}_bench_f32_split.json" 2>> "$OUT/bench.err"
+$PY --steps 4 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
+
+# 2. kernel trace of the bench command
+rm -rf /tmp/prof_kt
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $PY --steps 8 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/rocprof_kt.err"
+DB=$(find /tmp/prof_kt -name '*.db' | head -1)
+python $ROOT/tools/rocpd_stats.py "$DB" > "$OUT/${TAG}_rocprofv3_kernel_stats.md"
+WIN=$(python -c "import json; d=json.load(open('$OUT/${TAG}_bench_under_rocprofv3.json')); print(d['ms_per_step'] * d['steps'])")
+python $ROOT/tools/rocpd_stats.py "$DB" --window-ms "$WIN" > "$OUT/${TAG}_rocprofv3_kernel_stats_timed_region.md"
+python $ROOT/tools/rocpd_shapes.py "$DB" > "$OUT/${TAG}_rocprofv3_kernel_shapes.md"
+python $ROOT/tools/rocpd_gaps.py "$DB" --window-ms "$WIN" > "$OUT/${TAG}_gpu_idle_gaps.txt"
+
+# 3. counter passes (one counter set per run)
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES"; do
+    N=$(echo $C | tr ' ' '_')
+    rm -rf /tmp/prof_$N
+    rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 4 --warmup 0 --no-cpu-baseline > /dev/null 2> "$OUT/rocprof_$N.err"
+done
+F=$(find /tmp/prof_FETCH_SIZE -name '*.db' | head -1)
+W=$(find /tmp/prof_WRITE_SIZE -name '*.db' | head -1)
+M=$(find /tmp/prof_SQ_VALU_MFMA_BUSY_CYCLES_GRBM_GUI_ACTIVE -name '*.db' | head -1)
+M2=$(find /tmp/prof_SQ_INSTS_VALU_MFMA_MOPS_F32_SQ_BUSY_CYCLES -name '*.db' | head -1)
+python $ROOT/tools/rocpd_traffic.py "$F" "$W" gemm_f32 > "$OUT/${TAG}_pmc_gemm_traffic.json"
+python $ROOT/tools/rocpd_pmc.py "$F" "$W" > "$OUT/${TAG}_pmc_fetch_write_by_kernel.md"
+python $ROOT/tools/rocpd_pmc.py "$M" "$M2" > "$OUT/${TAG}_pmc_mfma_by_kernel.md"
+python $ROOT/tools/rocpd_mfma.py "$M" > "$OUT/${TAG}_pmc_mfma_utilisation.md"
+
+# 4. kernel microbenchmarks
+python $ROOT/tools/bench_gemm_cfg.py > "$OUT/${TAG}_gemm_tile_configs.log" 2>&1
+python $ROOT/tools/bench_kernels.py > "$OUT/${TAG}_kernel_microbench.log" 2>&1
+ls -la "$OUT"

@@ -1,4 +1,8 @@
-"""GPU idle time between kernels in a rocprofv3 kernel trace (single stream): where the host is the bottleneck."""
+"""GPU idle time between kernels in a rocprofv3 kernel trace (single stream): where the host is the bottleneck.
+
+    python tools/rocpd_gaps.py <db> [fraction of the trace to keep, default 0.6]
+    python tools/rocpd_gaps.py <db> --window-ms 1569      # the last 1569 ms (= the bench's timed region)
+"""
 import re
 import sqlite3
 import sys
@@ -10,10 +14,13 @@ def short(name):
 
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
-# keep the last `frac` of the trace (the timed searches), default 60 %
-frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.6
-t0, t1 = rows[0][1], rows[-1][2]
-cut = t1 - (t1 - t0) * frac
+# keep the last `frac` of the trace (the timed searches), default 60 %, or an explicit window
+t0, t1 = rows[0][1], max(r[2] for r in rows)
+if len(sys.argv) > 3 and sys.argv[2] == "--window-ms":
+    cut = t1 - float(sys.argv[3]) * 1e6
+else:
+    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.6
+    cut = t1 - (t1 - t0) * frac
 rows = [r for r in rows if r[1] >= cut]
 busy = sum(e - s for _, s, e in rows)
 span = rows[-1][2] - rows[0][1]

@@ -23,6 +23,7 @@ import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
+from scipy.interpolate import UnivariateSpline      # FITPACK fit on the host, as the reference (:265)
 
 from . import _lib
 from .video import FrameStore, open_video
@@ -298,7 +299,6 @@ class TStarSearcher:
         verification batch so the GPU works while the host fits the spline (verification does
         not read P, and its score overwrites are applied after the histories are stored, exactly
         in the reference's order)."""
-        from scipy.interpolate import UnivariateSpline
         vx, vy = self._state.apply_grid(secs, d_conf)
         ctx = overlap() if overlap is not None else None
         spline = UnivariateSpline(vx, vy, s=0.5)                  # FITPACK fit on the host, as :265
