@@ -53,11 +53,19 @@ using Cfg128 = Cfg<2, 2, 2>;
 using Cfg64N = Cfg<1, 2, 2>;
 using Cfg64 = Cfg<1, 1, 4>;
 
-// Epilogue shared by the f32 and the bf16-weight tiles.  C/D layout of the 32x32 MFMA:
+// Epilogue shared by the f32 and the bf16-pipe tiles.  C/D layout of the 32x32 MFMA:
 // col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[CF::TM][CF::TN], const int m0, const int n0,
-                                              const int wm, const int wn, const int l31, const int h) {
+//
+// Structure matters here: with one bounds-checked store per basic block the compiler has to re-wait
+// (s_waitcnt vmcnt(0)) for the bias / residual loads in EVERY block, which also waits for the previous
+// store's write acknowledgement -- 64 serialised round trips (~300 cycles each, ~20k cycles per tile,
+// measured as a flat C-bytes / 4 TB/s surcharge per launch).  So: per 32x32 sub-tile all loads (residual,
+// position embedding) are issued first, the 16 results are formed in registers, then the 16 stores go out
+// back to back; tiles that lie completely inside M (all but the last row panel) take an unguarded path
+// without any per-element branch.
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH, bool GUARD>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[CF::TM][CF::TN], const int m0, const int n0,
+                                                   const int wm, const int wn, const int l31, const int h) {
     constexpr int TM = CF::TM, TN = CF::TN;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -65,25 +73,44 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[C
         const float bv = HAS_BIAS ? g.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * h;
+            size_t off[16];
+            float extra[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < g.M) {
-                    float v = acc[i][j][r] + bv;
-                    v = epi_act(v, ACT);
-                    size_t orow = row;
-                    if (PATCH) {
-                        // patch-embed rows (b, p) -> token rows (b, 1 + p), + position embedding
-                        const int b = row / g.patch_np, p = row - b * g.patch_np;
-                        orow = (size_t)b * (g.patch_np + 1) + 1 + p;
-                        v += g.pos[(size_t)(1 + p) * g.N + col];
-                    }
-                    if (HAS_RES) v += g.res[orow * g.ldc + col];
-                    g.C[orow * g.ldc + col] = v;
+                int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (GUARD) row = row < g.M ? row : g.M - 1;          // loads stay in bounds; the store is predicated
+                size_t orow = row;
+                float e = 0.f;
+                if (PATCH) {
+                    // patch-embed rows (b, p) -> token rows (b, 1 + p), + position embedding
+                    const int b = row / g.patch_np, p = row - b * g.patch_np;
+                    orow = (size_t)b * (g.patch_np + 1) + 1 + p;
+                    e = g.pos[(size_t)(1 + p) * g.N + col];
                 }
+                off[r] = orow * g.ldc + col;
+                if (HAS_RES) e += g.res[off[r]];
+                extra[r] = e;
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = epi_act(acc[i][j][r] + bv, ACT);
+                if (PATCH || HAS_RES) v[r] += extra[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!GUARD || rbase + (r & 3) + 8 * (r >> 2) < g.M) g.C[off[r]] = v[r];
             }
         }
     }
+}
+
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[CF::TM][CF::TN], const int m0, const int n0,
+                                              const int wm, const int wn, const int l31, const int h) {
+    if (m0 + CF::BM <= g.M) gemm_epilogue_impl<CF, ACT, HAS_BIAS, HAS_RES, PATCH, false>(g, acc, m0, n0, wm, wn, l31, h);
+    else gemm_epilogue_impl<CF, ACT, HAS_BIAS, HAS_RES, PATCH, true>(g, acc, m0, n0, wm, wn, l31, h);
 }
 
 // ---------------------------------------------------------------------------------------------
