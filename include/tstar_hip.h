@@ -195,7 +195,7 @@ int tstar_ssim_pairwise(const uint8_t* d_gt, int G, const uint8_t* d_pred, int P
 int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                    int M, int N, int K, int act, void* stream);
 /* same with the block tile forced: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = hybrid (128x128 + 64x128 tail);
- * -1 = the launcher's choice */
+ * -1 = the launcher's choice; 16 + n = hybrid with the first n row tiles of 128 rows big (tile-policy sweeps) */
 int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                        int M, int N, int K, int act, int tile_cfg, void* stream);
 /* bf16-weight GEMM (diagnostic): W is rounded to bfloat16 on the device, A is split exactly; synchronises */

@@ -444,37 +444,36 @@ static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
     return TSTAR_OK;
 }
 
-// Tile choice from a wave model calibrated on MI355X (tools/lab/gemm_lab.hip): with
-// w = blocks / resident slots (256 CUs x blocks per CU), efficiency ~ e_cfg * w / (w + 0.5) for
-// w > 1 (half a wave of tail on average) and e_cfg * w below one wave.  e_cfg is the measured
-// steady-state rate of the tile shape relative to 128x128 (the narrower tiles re-stage the
-// operands more often; on wide-N problems 64x128 drops to 0.89).
-// Returns 0/1/2 for a pure grid, or 3 for the hybrid launch with *m_split set (time in units of
-// one 128x128 tile on a fully resident CU pair).
+// Tile choice, calibrated on MI355X (tools/sweep_hybrid_split.py, tools/bench_gemm_cfg.py).  Blocks are
+// dispatched in index order onto 512 resident slots (256 CUs x 2 blocks; 1024 quarter-size slots for 64x64):
+//  * under a quarter / half of a wave of 128x128 tiles the smaller tiles win simply by putting a block on every CU;
+//  * between half a wave and one wave a smoothed wave model decides (w = blocks / slots, time ~ w + 0.5 beyond
+//    one wave, e_cfg = steady-state rate of the narrower tiles relative to 128x128);
+//  * from one full wave on, the HYBRID launch is never worse than any pure grid and up to 15 % better: as many
+//    whole 512-block waves of 128x128 tiles as fit, the remaining rows as 64x128 tiles, which arrive last and
+//    fill the tail at half the granularity.
+// Returns 0/1/2 for a pure grid, or 3 for the hybrid launch with *m_split set.
 static int pick_cfg(int M, int N, int* m_split) {
     *m_split = 0;
     const int nt = N / 128;
     const int b128 = cdiv(M, 128) * nt;
-    if (b128 <= 256) return 2;                               // under one block per CU: smallest tile
+    if (b128 <= 128) return 2;                               // 64x64: up to 512 blocks
+    if (b128 <= 256) return 1;                               // 64x128: up to 512 blocks
+    if (b128 >= 512) {
+        const int big_rows = ((b128 / 512) * 512 / nt) * 128;  // rows covered by whole waves of 128x128 tiles
+        if (big_rows >= M) return 0;
+        *m_split = big_rows;
+        return 3;
+    }
     auto waves = [](double w) { return w <= 1.0 ? 1.0 : w + 0.5; };
-    const double e64n = N <= 1024 ? 0.96 : 0.92, e64 = 0.93;
+    const double e64n = 0.96, e64 = 0.93;
     const double t128 = waves(b128 / 512.0);
     const double t64n = waves((double)cdiv(M, 64) * nt / 512.0) * 0.5 / e64n;
-    const double t64 = waves((double)cdiv(M, 64) * (N / 64) / 1024.0) * 0.5 / e64;   // 1024 quarter-size blocks = half a unit
-    // hybrid: as many whole 512-block waves of 128x128 tiles as fit, the rest as 64x128 tiles
-    double thyb = 1e30;
-    int split = 0;
-    const int full_rows = (512 / nt) > 0 ? ((b128 / 512) * 512 / nt) * 128 : 0;   // rows covered by whole waves
-    if (N <= 1024 && full_rows >= 128 && full_rows < M) {      // wide-N tails do not pay (measured)
-        split = full_rows;
-        const double rest = (double)cdiv(M - split, 64) * nt / 512.0;
-        thyb = (double)(split / 128) * nt / 512.0 + (rest <= 1.0 ? 1.0 : rest + 0.5) * 0.5 / e64n;
-    }
+    const double t64 = waves((double)cdiv(M, 64) * (N / 64) / 1024.0) * 0.5 / e64;   // 1024 quarter-size slots
     int best = 0;
     double tb = t128;
     if (t64n < tb) { tb = t64n; best = 1; }
     if (t64 < tb) { tb = t64; best = 2; }
-    if (thyb < tb * 0.985) { best = 3; *m_split = split; }
     return best;
 }
 
@@ -486,6 +485,10 @@ static int launch_mode(const GemmArgs& g, hipStream_t stream) {
     if (forced == 3) {                                       // forced hybrid: half of the row tiles big
         m_split = (cdiv(g.M, 128) / 2) * 128;
         if (m_split == 0) cfg = 1;
+    } else if (forced >= 16) {                               // diagnostic: hybrid with (forced - 16) big row tiles
+        m_split = (forced - 16) * 128;
+        if (m_split > (g.M / 128) * 128) m_split = (g.M / 128) * 128;
+        cfg = m_split == 0 ? 1 : 3;
     }
     if (cfg == 3) {
         GemmArgs h = g;
@@ -509,7 +512,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t stream) {
     TSTAR_REQUIRE(g.N % 128 == 0, "gemm_f32: N must be a multiple of 128");
     TSTAR_REQUIRE(g.K % BK == 0, "gemm_f32: K must be a multiple of 32");
     TSTAR_REQUIRE(g.lda % 4 == 0 && g.K % 4 == 0, "gemm_f32: rows must be 16-byte aligned");
-    TSTAR_REQUIRE(g.tile_cfg >= -1 && g.tile_cfg <= 3, "gemm_f32: tile_cfg must be -1..3");
+    TSTAR_REQUIRE((g.tile_cfg >= -1 && g.tile_cfg <= 3) || g.tile_cfg >= 16, "gemm_f32: tile_cfg must be -1..3 (or 16 + big row tiles)");
     const bool bias = g.bias != nullptr, res = g.res != nullptr, patch = g.pos != nullptr;
     if (patch) {
         TSTAR_REQUIRE(!bias && !res && g.act == ACT_NONE && g.patch_np > 0, "gemm_f32: patch epilogue takes no bias/res/act");

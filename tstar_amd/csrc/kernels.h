@@ -18,7 +18,7 @@ struct GemmArgs {
     int M, N, K, lda, ldc;
     int act;             // ACT_*
     int patch_np;        // patches per image (576) for the patch-embed epilogue
-    int tile_cfg;        // -1 auto; 0 = 128x128, 1 = 64x128, 2 = 64x64 block tile, 3 = hybrid 128x128 + 64x128 tail
+    int tile_cfg;        // -1 auto; 0 = 128x128, 1 = 64x128, 2 = 64x64 block tile, 3 = hybrid 128x128 + 64x128 tail (half/half); 16 + n = hybrid with n big row tiles (diagnostic)
     int m_split;         // hybrid launch: rows [0, m_split) use 128-row tiles (set by the launcher)
 };
 int gemm_f32(const GemmArgs& g, hipStream_t stream);
