@@ -29,7 +29,7 @@ namespace tstar {
 constexpr int HD = 64, KB = 32, K_LD = HD + 4;
 
 template <int MODE>
-__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int T, int heads, int qtiles,
                                                             const uint8_t* __restrict__ key_mask) {
     __shared__ __attribute__((aligned(16))) float Ks[2][KB][K_LD];
