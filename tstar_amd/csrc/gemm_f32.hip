@@ -29,6 +29,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
+#include <type_traits>
 
 namespace tstar {
 
@@ -206,24 +207,29 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[NA];
-    u32x4 rb[NWT][NB];
-    auto gload = [&](int kt) {
+    // Register prefetch is TWO K tiles deep (sets 0/1): with the bf16 pipe a K tile is only ~770 matrix-pipe
+    // cycles per wave, less than one L2 round trip, so a one-deep prefetch (as in the f32 tile, whose K tile
+    // is 4096 cycles) would expose the load latency at every tile.
+    f32x4 ra[2][NA];
+    u32x4 rb[2][NWT][NB];
+    auto gload = [&](auto SET, int kt) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+        for (int i = 0; i < NA; ++i) ra[st][i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            rb[0][i] = *reinterpret_cast<const u32x4*>(g.Wb + bo[i] + kt * BK);
-            if constexpr (NWT == 2) rb[NWT - 1][i] = *reinterpret_cast<const u32x4*>(g.Wb2 + bo[i] + kt * BK);
+            rb[st][0][i] = *reinterpret_cast<const u32x4*>(g.Wb + bo[i] + kt * BK);
+            if constexpr (NWT == 2) rb[st][NWT - 1][i] = *reinterpret_cast<const u32x4*>(g.Wb2 + bo[i] + kt * BK);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](auto SET, int buf) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value;
         char* base = smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             u32x2 sp[NAT];
-            if constexpr (WMODE == 2) split4_bf16x2(ra[i], sp);
-            else split4_bf16x3(ra[i], sp);
+            if constexpr (WMODE == 2) split4_bf16x2(ra[st][i], sp);
+            else split4_bf16x3(ra[st][i], sp);
             const int off = bfw_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
 #pragma unroll
             for (int k = 0; k < NAT; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
@@ -232,18 +238,10 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
         for (int w = 0; w < NWT; ++w)
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                *reinterpret_cast<u32x4*>(base + NAT * A_T + w * W_T + bfw_off(wr + 64 * i, wc)) = rb[w][i];
+                *reinterpret_cast<u32x4*>(base + NAT * A_T + w * W_T + bfw_off(wr + 64 * i, wc)) = rb[st][w][i];
     };
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    const int nk = g.K / BK;
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
-        const char* base = smem + cur * BUF;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const char* base = smem + buf * BUF;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                       // two K = 16 steps per tile
@@ -271,9 +269,26 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (more) lstore(cur ^ 1);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int nk = g.K / BK;
+    gload(S0{}, 0);
+    if (nk > 1) gload(S1{}, 1);
+    lstore(S0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even tile: LDS buffer 0; set 0 is free again (tile kt went to LDS), set 1 holds tile kt+1
+        if (kt + 2 < nk) gload(S0{}, kt + 2);
+        compute(0);
+        if (kt + 1 < nk) lstore(S1{}, 1);
         __syncthreads();
-        cur ^= 1;
+        if (kt + 1 >= nk) break;
+        // odd tile: LDS buffer 1; set 1 is free, set 0 holds tile kt+2
+        if (kt + 3 < nk) gload(S1{}, kt + 3);
+        compute(1);
+        if (kt + 2 < nk) lstore(S0{}, 0);
+        __syncthreads();
     }
     gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
 }
