@@ -58,6 +58,33 @@ def test_gemm_tile_configs(lib, cfg, M, N, K):
     assert (dC.cpu() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(73856, 768, 768, 0, True), (30004, 2304, 768, 1, False), (2308, 3072, 768, 0, False),
+                                           (1155, 768, 3072, 2, False)])
+def test_gemm_result_independent_of_tiling(lib, M, N, K, act, res):
+    """Full-size property: every tile shape, the hybrid launch at any split and the launcher's own choice give
+    BIT-IDENTICAL outputs (each element is one MFMA accumulation chain over K in the same order), including the
+    guarded last row panel, the fused activation and the in-place residual."""
+    g = torch.Generator().manual_seed(M + N)
+    dA = torch.randn(M, K, generator=g).cuda()
+    dW = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    db = torch.randn(N, generator=g).cuda()
+    dR = torch.randn(M, N, generator=g).cuda() if res else None
+    mt = (M + 127) // 128
+    outs = {}
+    for cfg in (0, 1, 2, 3, -1, 16 + 1, 16 + mt // 3, 16 + mt):
+        dC = dR.clone() if res else torch.full((M, N), float("nan"), device="cuda")
+        _check(lib.tstar_gemm_f32_cfg(dA.data_ptr(), dW.data_ptr(), dC.data_ptr(), db.data_ptr(), dC.data_ptr() if res else None,
+                                      M, N, K, act, cfg, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        outs[cfg] = dC
+    assert torch.isfinite(outs[0]).all()
+    for cfg, o in outs.items():
+        assert torch.equal(o, outs[0]), cfg
+    with pytest.raises(Exception):
+        _check(lib.tstar_gemm_f32_cfg(dA.data_ptr(), dW.data_ptr(), outs[0].data_ptr(), db.data_ptr(), None, M, N, K, act, 7,
+                                      torch.cuda.current_stream().cuda_stream))
+
+
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K,act", [(577, 768, 3072, 0), (130, 256, 64, 1), (1154, 512, 768, 2), (25388, 768, 768, 0)])
 def test_gemm_bf16_weights_exact_split(lib, cfg, M, N, K, act):

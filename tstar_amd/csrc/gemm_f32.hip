@@ -12,9 +12,10 @@
 //  * 128x128x32 block tile, 256 threads = 4 waves (2x2), each wave 64x64 =
 //    2x2 MFMA tiles (64 accumulator VGPRs).  2 blocks per CU so one block's
 //    MFMA stream covers the other's barrier / LDS-write bubbles.  Two smaller
-//    tile shapes (64x128, 64x64) share the code; the launcher picks per shape
-//    from a wave-quantisation model (narrow-N and small-M launches otherwise
-//    lose up to 25 % / 4x to the tail).
+//    tile shapes (64x128, 64x64) share the code; the launcher (pick_cfg) uses
+//    them for grids under one wave of 128x128 tiles and, from one full wave
+//    on, launches whole waves of 128x128 tiles followed by a 64x128 tail
+//    (the hybrid kernel), so the last wave is quantised at half a tile.
 //  * both operands are K-contiguous (activations row-major, nn.Linear weight
 //    [out,in]) -> identical staging for A and W: global_load_dwordx4 ->
 //    ds_write_b128 into a [128][32+4] padded tile (row stride 144 B makes the
