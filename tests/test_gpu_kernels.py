@@ -230,7 +230,7 @@ def _attn_ref(qkv, B, T, heads, mask=None):
     return torch.matmul(att, v).transpose(1, 2).reshape(B * T, D)
 
 
-@pytest.mark.parametrize("B,T,heads", [(1, 577, 12), (2, 577, 12), (3, 16, 8), (1, 33, 2), (1, 128, 1), (1, 1, 1)])
+@pytest.mark.parametrize("B,T,heads", [(1, 577, 12), (2, 577, 12), (3, 16, 8), (1, 33, 2), (1, 128, 1), (1, 1, 1), (2, 97, 3), (1, 600, 2)])
 def test_attention_full(lib, B, T, heads):
     g = torch.Generator().manual_seed(B * 1000 + T + heads)
     D = heads * 64
@@ -244,14 +244,18 @@ def test_attention_full(lib, B, T, heads):
     assert (out.cpu() - ref).abs().max().item() < 2e-5
 
 
-def test_attention_spiked_scores(lib):
-    """Force large online-softmax rescales: one key dominates late in the sequence."""
+@pytest.mark.parametrize("last_key_spike", [False, True])
+def test_attention_spiked_scores(lib, last_key_spike):
+    """Force large online-softmax rescales: one key dominates late in the sequence; with ``last_key_spike`` it is
+    the straggler key 576 that the kernel folds in after its block loop."""
     B, T, heads = 1, 577, 2
     g = torch.Generator().manual_seed(11)
     D = heads * 64
     qkv = torch.randn(B * T, 3 * D, generator=g)
     qkv[500, D:2 * D] *= 40.0        # huge key late -> max jumps at key block 15
     qkv[3, D:2 * D] *= 25.0          # and an early big one
+    if last_key_spike:
+        qkv[576, D:2 * D] *= 60.0
     ref = _attn_ref(qkv, B, T, heads)
     out = torch.empty((B * T, D), device="cuda")
     dqkv = qkv.cuda()

@@ -16,6 +16,8 @@
 //    are already in B-operand layout for O^T = V^T P^T -- no LDS round trip,
 //    no permutes.  O^T columns are queries too, so the online-softmax rescale is
 //    lane-local.
+//  * T = 32 n + 1 (577 = 576 patches + CLS): the straggler key is folded in after
+//    the block loop with VALU ops (tail_key) instead of a 19th, 97 % empty block.
 //  * K/V tiles (32 keys) are staged global -> VGPR -> LDS, double-buffered, one
 //    barrier per tile; K rows padded to 68 floats (conflict-free ds_read_b128),
 //    V read as ds_read_b32 rows (two 32-lane halves never conflict).
@@ -66,7 +68,10 @@ __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __re
     const float* vbase = qkv + 2 * D + head * HD + f4 * 4;
     auto krow = [&](int key) { return (rowbase + (key < T ? key : T - 1)) * D3; };
 
-    const int nkb = (T + KB - 1) / KB;
+    // T = 32 n + 1 (the ViT's 576 patches + CLS): the single straggler key is folded in after the loop with a
+    // few VALU ops instead of costing a whole 32-key MFMA block (1/19 of the kernel at T = 577)
+    const bool tail_key = MODE == 0 && (T % KB) == 1;
+    const int nkb = tail_key ? T / KB : (T + KB - 1) / KB;
     f32x4 rk[2], rv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __re
             __builtin_amdgcn_s_setprio(0);
             // masks (only the last key block of the full-attention mode can hold invalid keys) + block max
             float mb = -INFINITY;
-            if (MODE == 1 || kb == nkb - 1) {
+            if (MODE == 1 || (!tail_key && kb == nkb - 1)) {
                 const int key0 = kb * KB + 4 * h;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -166,6 +171,35 @@ __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __re
         }
         __syncthreads();
         cur ^= 1;
+    }
+
+    if (tail_key && wave_active) {
+        const size_t ro = (rowbase + (T - 1)) * D3 + head * HD;
+        // score of every query of this wave against key T-1: the lane holds half of the query's 64 dims
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(qkv + ro + D + 8 * c + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sx += kv[e] * qf[c][e];
+        }
+        sx += __shfl_xor(sx, 32);
+        const float m_new = fmaxf(m_run, sx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // 0 when no key came before (T = 1)
+        const float p = __builtin_amdgcn_exp2f(sx - m_new);
+        l_run = l_run * alpha + p;
+        m_run = m_new;
+        // O^T[d][q] = O^T[d][q] * alpha + p * V[T-1][d], d = (r&3) + 8(r>>2) + 4h (+32 for the second tile)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(qkv + ro + 2 * D + 8 * g4 + 4 * h);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(qkv + ro + 2 * D + 32 + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o0[g4 * 4 + e] = o0[g4 * 4 + e] * alpha + p * v0[e];
+                o1[g4 * 4 + e] = o1[g4 * 4 + e] * alpha + p * v1[e];
+            }
+        }
     }
 
     if (q < T) {
