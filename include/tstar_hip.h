@@ -63,7 +63,8 @@ typedef struct tstar_owl tstar_owl;
  *   TSTAR_WEIGHTS_BF16 (1) (BASELINE config 5, "bf16 ViT weights"): every GEMM weight matrix is also kept
  *     as bfloat16 (round to nearest even; exact if the blob already holds bf16 values) and the GEMMs run
  *     on the bf16 matrix pipe with the float32 activations split exactly into three bf16 terms -- an
- *     f32-accumulated product of f32 activations and bf16 weights.
+ *     f32-accumulated product of f32 activations and bf16 weights.  The vision tower's attention runs on the
+ *     bf16 pipe as well in modes 1 and 2 (f32-split operands: two bf16 terms each, 3 products, f32 accumulation).
  *   TSTAR_WEIGHTS_F32_SPLIT (2): float32 checkpoints on the bf16 matrix pipe: each weight is kept as two
  *     bfloat16 terms hi + lo and each activation is split into two terms on the fly (round to nearest,
  *     16 significand bits per operand); C += a_lo*w_hi + a_hi*w_lo + a_hi*w_hi with exact products and f32
@@ -208,6 +209,9 @@ int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const fl
 /* qkv [B*T, 3*heads*64] -> out [B*T, heads*64]; mode 0 full, 1 causal + key mask u8 [B,T] */
 int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode,
                         const uint8_t* d_key_mask, void* stream);
+
+/* full attention with f32-split operands on the bf16 matrix pipe (what the bf16-pipe weights modes use) */
+int tstar_attention_split(const float* d_qkv, float* d_out, int B, int T, int heads, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream, for bench.py's roofline leg.
  * category 0 = gemm_f32_kernel, 1 = attention_f32_kernel.  enable(n > 0) resets the counters and times every

@@ -266,6 +266,51 @@ def test_attention_spiked_scores(lib, last_key_spike):
     assert (out.cpu() - ref).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize("B,T,heads", [(1, 577, 12), (2, 577, 3), (1, 33, 2), (1, 128, 1), (1, 1, 1), (2, 97, 3), (1, 600, 2), (1, 64, 1)])
+def test_attention_split(lib, B, T, heads):
+    """Full attention with f32-split operands on the bf16 matrix pipe (the bf16-pipe weights modes): each operand
+    carries 16 significand bits, so the result tracks the float64 reference to ~1e-5 of the value range (the exact-f32
+    kernel: ~1e-6), far inside what the detector-score contract (1e-3) needs."""
+    g = torch.Generator().manual_seed(B * 1000 + T + heads)
+    D = heads * 64
+    qkv = torch.randn(B * T, 3 * D, generator=g)
+    qkv[:, :D] *= 3.0                                    # scores up to ~ +-25: a peaky softmax
+    ref = _attn_ref(qkv.double(), B, T, heads)
+    out = torch.full((B * T, D), float("nan"), device="cuda")
+    out32 = torch.empty((B * T, D), device="cuda")
+    dqkv = qkv.cuda()
+    _check(lib.tstar_attention_split(dqkv.data_ptr(), out.data_ptr(), B, T, heads, torch.cuda.current_stream().cuda_stream))
+    _check(lib.tstar_attention_f32(dqkv.data_ptr(), out32.data_ptr(), B, T, heads, 0, None,
+                                   torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    err = (out.cpu().double() - ref).abs().max().item()
+    err32 = (out32.cpu().double() - ref).abs().max().item()
+    assert err < 2e-4, (err, err32)
+    assert err < 60 * err32 + 1e-5, (err, err32)
+
+
+def test_attention_split_spiked(lib):
+    """Large online-softmax rescales (a dominant key late, and the straggler key 576 dominating) in the split kernel."""
+    B, T, heads = 1, 577, 2
+    D = heads * 64
+    for spike_last in (False, True):
+        g = torch.Generator().manual_seed(11)
+        qkv = torch.randn(B * T, 3 * D, generator=g)
+        qkv[500, D:2 * D] *= 40.0
+        qkv[3, D:2 * D] *= 25.0
+        if spike_last:
+            qkv[576, D:2 * D] *= 60.0
+        ref = _attn_ref(qkv.double(), B, T, heads)
+        out = torch.empty((B * T, D), device="cuda")
+        dqkv = qkv.cuda()
+        _check(lib.tstar_attention_split(dqkv.data_ptr(), out.data_ptr(), B, T, heads, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        # a dominant logit of magnitude ~300 carries an absolute error of ~300 * 2^-17 = 2e-3 in the exponent
+        assert (out.cpu().double() - ref).abs().max().item() < 2e-2
+
+
 def test_attention_causal_padded(lib):
     B, T, heads = 4, 16, 8
     g = torch.Generator().manual_seed(5)

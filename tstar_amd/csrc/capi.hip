@@ -166,7 +166,9 @@ static int run_encoder(tstar_owl* h, const LayerW* layers, int nlayers, int B, i
         const LayerW& w = layers[l];
         RC(layernorm_f32(h->x, h->xn, w.ln1_w, w.ln1_b, M, D, s));
         RC(gemm_f32(mk_gemm(h, h->xn, w.qkv_w, h->qkv, w.qkv_b, nullptr, M, 3 * D, D, D, 3 * D, ACT_NONE), s));
-        RC(attention_f32(h->qkv, h->att, B, T, heads, mode, key_mask, s));
+        // full attention in the opt-in bf16-pipe modes runs on the bf16 matrix pipe too (f32-split operands)
+        if (mode == 0 && h->weights_mode != TSTAR_WEIGHTS_F32) RC(attention_split(h->qkv, h->att, B, T, heads, s));
+        else RC(attention_f32(h->qkv, h->att, B, T, heads, mode, key_mask, s));
         RC(gemm_f32(mk_gemm(h, h->att, w.out_w, h->x, w.out_b, h->x, M, D, D, D, D, ACT_NONE), s));
         RC(layernorm_f32(h->x, h->xn, w.ln2_w, w.ln2_b, M, D, s));
         RC(gemm_f32(mk_gemm(h, h->xn, w.fc1_w, h->hid, w.fc1_b, nullptr, M, FF, D, D, FF, ACT_QGELU), s));
@@ -535,6 +537,11 @@ int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int head
                         void* stream) {
     TSTAR_REQUIRE(d_qkv && d_out, "tstar_attention_f32: null argument");
     return attention_f32(d_qkv, d_out, B, T, heads, mode, d_key_mask, (hipStream_t)stream);
+}
+
+int tstar_attention_split(const float* d_qkv, float* d_out, int B, int T, int heads, void* stream) {
+    TSTAR_REQUIRE(d_qkv && d_out, "tstar_attention_split: null argument");
+    return attention_split(d_qkv, d_out, B, T, heads, (hipStream_t)stream);
 }
 
 }  // extern "C"

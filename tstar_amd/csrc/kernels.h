@@ -42,4 +42,7 @@ int merge_cls_ln(const float* x, float* feats, const float* post_w, const float*
 int attention_f32(const float* qkv, float* out, int B, int T, int heads, int mode,
                   const uint8_t* key_mask, hipStream_t s);
 
+// the same (mode 0 only) on the bf16 matrix pipe: every f32 operand as two bf16 terms, 3 products per MFMA step
+int attention_split(const float* qkv, float* out, int B, int T, int heads, hipStream_t s);
+
 }  // namespace tstar
