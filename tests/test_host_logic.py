@@ -42,6 +42,16 @@ def test_no_cpu_fallback_without_gpu():
         OWLInterface(device="cpu", synthetic_seed=0)
 
 
+def test_heuristic_factory_names():
+    """initialize_heuristic keeps the reference's type names (TStarFramework.py:171-187): 'owl-vit' is built,
+    'yolo-World' and unknown names raise NotImplementedError like the reference's else branch."""
+    from tstar_amd.interface_heuristic import initialize_heuristic
+    with pytest.raises(NotImplementedError, match="yolo-World"):
+        initialize_heuristic("yolo-World")
+    with pytest.raises(NotImplementedError, match="not implemented"):
+        initialize_heuristic("frcnn")
+
+
 def test_product_does_not_import_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "tstar_amd")):
         for f in files:

@@ -184,4 +184,10 @@ def initialize_heuristic(heuristic_type: str = "owl-vit", **kwargs) -> Heuristic
     """Factory with the reference's signature (TStarFramework.py:171-187)."""
     if heuristic_type == "owl-vit":
         return OWLInterface(model_name_or_path="google/owlvit-base-patch32", **kwargs)
+    if heuristic_type == "yolo-World":
+        # the reference wires YOLO-World through mmdet/mmyolo and a repository cloned at install time
+        # (TStarFramework.py:178-184, install.sh); none of that source is in the reference tree, so there is
+        # nothing to pin a HIP implementation against (DESIGN.md section 8)
+        raise NotImplementedError("Heuristic type 'yolo-World' is not built in tstar_amd (its detector source is "
+                                  "not part of the reference tree); use 'owl-vit'.")
     raise NotImplementedError(f"Heuristic type '{heuristic_type}' is not implemented.")
