@@ -55,7 +55,7 @@ def parse():
                          "--nframes 14400 --grid 15 --search-nframes 32 this is configs[4]")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="independent searches in flight per GPU (host threads, one HIP stream + one scorer "
-                         "workspace each); 2 fills kernel tails and gives ~+11 % throughput, but overlapping "
+                         "workspace each); 2 fills kernel tails and gives ~+5 % throughput, but overlapping "
                          "launches inflate per-launch durations, so the roofline leg is reported at 1")
     ap.add_argument("--lockstep", type=int, default=4,
                     help="independent (video, question) items advanced in lock-step per detector batch "

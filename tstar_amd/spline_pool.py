@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import atexit
 import os
+import threading
 import struct
 import subprocess
 import sys
@@ -42,6 +43,7 @@ class SplinePool:
         if workers < 1:
             raise ValueError("SplinePool needs at least one worker")
         self._procs: List[subprocess.Popen] = []
+        self._lock = threading.Lock()           # one caller at a time owns the pipes (bench.py --concurrency)
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
         try:
             for _ in range(workers):
@@ -97,17 +99,20 @@ class SplinePool:
         if not self._procs:
             raise SplinePoolError("spline pool is closed")
         out: List[Optional[Tuple[np.ndarray, np.ndarray, int]]] = [None] * len(problems)
-        w = len(self._procs)
-        try:
-            for lo in range(0, len(problems), w):
-                chunk = problems[lo:lo + w]
-                for p, (x, y) in zip(self._procs, chunk):
-                    self._send(p, x, y, s)
-                for j, p in enumerate(self._procs[:len(chunk)]):
-                    out[lo + j] = self._recv(p)
-        except (OSError, SplinePoolError):
-            self.close()                    # a half-served pool cannot be resynchronised
-            raise
+        with self._lock:
+            if not self._procs:
+                raise SplinePoolError("spline pool is closed")
+            w = len(self._procs)
+            try:
+                for lo in range(0, len(problems), w):
+                    chunk = problems[lo:lo + w]
+                    for p, (x, y) in zip(self._procs, chunk):
+                        self._send(p, x, y, s)
+                    for j, p in enumerate(self._procs[:len(chunk)]):
+                        out[lo + j] = self._recv(p)
+            except (OSError, SplinePoolError):
+                self.close()                    # a half-served pool cannot be resynchronised
+                raise
         return out
 
 
