@@ -52,10 +52,11 @@ def parse():
     ap.add_argument("--search-nframes", type=int, default=8)
     ap.add_argument("--weights", choices=["f32", "bf16", "f32_split"], default="f32",
                     help="bf16 = BASELINE config 5 (bf16-rounded weights, exact-split bf16 MFMA GEMMs); with "
-                         "--nframes 14400 --grid 15 --search-nframes 32 this is configs[4]")
+                         "--nframes 14400 --grid 15 --search-nframes 32 this is configs[4].  f32_split = fp32 checkpoint "
+                         "with every operand carried as two bf16 terms on the bf16 matrix pipe (opt-in)")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="independent searches in flight per GPU (host threads, one HIP stream + one scorer "
-                         "workspace each); 2 fills kernel tails and gives ~+5 % throughput, but overlapping "
+                         "workspace each); 2 fills kernel tails and gives ~+5 %% throughput, but overlapping "
                          "launches inflate per-launch durations, so the roofline leg is reported at 1")
     ap.add_argument("--lockstep", type=int, default=4,
                     help="independent (video, question) items advanced in lock-step per detector batch "
