@@ -44,10 +44,10 @@ TARGETS, CUES = ["couch"], ["tv", "chair"]
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=16, help="grid side g (g*g frames per iteration)")
-    ap.add_argument("--max-batch", type=int, default=128, help="detector images per forward chunk")
+    ap.add_argument("--max-batch", type=int, default=256, help="detector images per forward chunk")
     ap.add_argument("--nframes", type=int, default=N_FRAMES)
     ap.add_argument("--search-nframes", type=int, default=8)
     ap.add_argument("--weights", choices=["f32", "bf16", "f32_split"], default="f32",
