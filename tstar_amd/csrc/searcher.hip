@@ -92,9 +92,10 @@ __device__ __forceinline__ double lerp75(double a, double b, double g) {
 __global__ __launch_bounds__(ST) void apply_grid_kernel(double* __restrict__ score, double* __restrict__ unvisited,
                                                         const int* __restrict__ secs, const double* __restrict__ conf,
                                                         int n, int N, int window, int* __restrict__ vis_x,
-                                                        double* __restrict__ vis_y, int* __restrict__ n_vis) {
+                                                        double* __restrict__ vis_y, int* __restrict__ n_vis, int use_lds) {
     __shared__ double s_lohi[2];
-    __shared__ int s_cnt[ST];
+    __shared__ int s_cnt[ST / 64];
+    extern __shared__ double s_dyn[];            // use_lds: [score N][conf n][secs n (int)]
     const int t = threadIdx.x;
     for (int i = t; i < n; i += ST) { unvisited[secs[i]] = 0.0; score[secs[i]] = conf[i]; }
     // order statistics of conf by rank counting (n <= a few hundred)
@@ -111,32 +112,57 @@ __global__ __launch_bounds__(ST) void apply_grid_kernel(double* __restrict__ sco
         if (rank == hi) s_lohi[1] = c;
     }
     __syncthreads();
+    // the spread is ONE lane walking the samples in draw order (order-dependent, in place); its working set is
+    // staged in LDS when it fits, so each step costs an LDS access instead of a global round trip
+    double* w_score = score;
+    const double* w_conf = conf;
+    const int* w_secs = secs;
+    if (use_lds) {
+        double* l_conf = s_dyn + N;
+        int* l_secs = reinterpret_cast<int*>(l_conf + n);
+        __threadfence_block();
+        __syncthreads();
+        for (int i = t; i < N; i += ST) s_dyn[i] = score[i];
+        for (int i = t; i < n; i += ST) { l_conf[i] = conf[i]; l_secs[i] = secs[i]; }
+        w_score = s_dyn; w_conf = l_conf; w_secs = l_secs;
+    }
+    __syncthreads();
     if (t == 0) {
         const double thr = lerp75(s_lohi[0], s_lohi[1], g);
         for (int i = 0; i < n; ++i) {            // draw order, in place (order-dependent)
-            if (conf[i] >= thr) {
-                const int f = secs[i];
+            if (w_conf[i] >= thr) {
+                const int f = w_secs[i];
                 for (int off = -window; off <= window; ++off) {
                     const int j = f + off;
                     if (j >= 0 && j < N) {
-                        const double v = score[f] / (double)((off < 0 ? -off : off) + 1);
-                        if (v > score[j]) score[j] = v;          // Python max(score[j], v)
+                        const double v = w_score[f] / (double)((off < 0 ? -off : off) + 1);
+                        if (v > w_score[j]) w_score[j] = v;          // Python max(score[j], v)
                     }
                 }
             }
         }
     }
     __syncthreads();
+    if (use_lds) {
+        for (int i = t; i < N; i += ST) score[i] = s_dyn[i];
+        __threadfence_block();
+        __syncthreads();
+    }
     // ordered compaction of the visited frames
     const int per = (N + ST - 1) / ST;
     const int b0 = t * per, b1 = (b0 + per < N) ? b0 + per : N;
     int cnt = 0;
     for (int i = b0; i < b1; ++i) cnt += unvisited[i] == 0.0;
-    s_cnt[t] = cnt;
+    // exclusive prefix of the per-thread counts: shuffle scan inside each wave, 16 wave totals through LDS
+    const int lane = t & 63, wv = t >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    if (lane == 63) s_cnt[wv] = incl;
     __syncthreads();
-    if (t == 0) { int acc = 0; for (int i = 0; i < ST; ++i) { int c = s_cnt[i]; s_cnt[i] = acc; acc += c; } *n_vis = acc; }
+    if (t == 0) { int acc = 0; for (int i = 0; i < ST / 64; ++i) { const int c = s_cnt[i]; s_cnt[i] = acc; acc += c; } *n_vis = acc; }
     __syncthreads();
-    int o = s_cnt[t];
+    int o = s_cnt[wv] + incl - cnt;
     for (int i = b0; i < b1; ++i)
         if (unvisited[i] == 0.0) { vis_x[o] = i; vis_y[o] = score[i]; ++o; }
 }
@@ -233,6 +259,17 @@ __device__ void block_cdf(const double* p, double* cdf, int N) {
             double acc;
             int i = 0;
             if (base == 0) { acc = s_buf[0]; i = 1; } else acc = s_carry;
+            // 16 values per step through registers: the LDS reads of a step are independent of the add chain, so
+            // only the f64 add latency is serial (a read-add-write loop pays the LDS latency per element: 8x slower)
+            for (; i + 16 <= n; i += 16) {
+                double r[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r[j] = s_buf[i + j];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { acc = acc + r[j]; r[j] = acc; }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s_buf[i + j] = r[j];
+            }
             for (; i < n; ++i) { acc = acc + s_buf[i]; s_buf[i] = acc; }
             s_carry = acc;
         }
@@ -398,8 +435,18 @@ int tstar_searcher_apply_grid(tstar_searcher* s, const int32_t* h_secs, const do
     for (int i = 0; i < n; ++i) TSTAR_REQUIRE(h_secs[i] >= 0 && h_secs[i] < s->N, "tstar_searcher_apply_grid: second out of range");
     hipStream_t st = (hipStream_t)stream;
     TSTAR_HIP_CHECK(hipMemcpyAsync(s->d_secs, h_secs, n * sizeof(int), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(apply_grid_kernel, dim3(1), dim3(ST), 0, st, s->score, s->unvisited, s->d_secs, d_conf, n, s->N, 5,
-                       s->d_vis_x, s->d_vis_y, s->d_flag);
+    // LDS working set of the window spread: score (N f64) + conf (n f64) + secs (n i32); global fallback beyond 144 KB
+    const size_t need = (size_t)s->N * 8 + (size_t)n * 12;
+    const int use_lds = need <= 144 * 1024;
+    const size_t dyn = use_lds ? need : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(apply_grid_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(apply_grid_kernel, dim3(1), dim3(ST), dyn, st, s->score, s->unvisited, s->d_secs, d_conf, n, s->N, 5,
+                       s->d_vis_x, s->d_vis_y, s->d_flag, use_lds);
     TSTAR_HIP_CHECK(hipGetLastError());
     TSTAR_HIP_CHECK(hipMemcpyAsync(h_n_visited, s->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     TSTAR_HIP_CHECK(hipStreamSynchronize(st));
