@@ -19,7 +19,11 @@ def _ulp_close(a, b, ulps=4):
     return np.all(np.abs(a - b) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b))))
 
 
-@pytest.mark.parametrize("N,g,seed", [(3600, 4, 0), (3600, 16, 1), (100, 4, 2), (14400, 15, 3), (777, 8, 4)])
+# sizes chosen to cross the kernels' internal boundaries: the 2048-element cumsum chunks (2049, 4097), the 16-value
+# register blocks (odd / prime N), N barely above g*g (17), and N = 19000 where the window spread's working set no
+# longer fits in LDS and the global-memory path runs
+@pytest.mark.parametrize("N,g,seed", [(3600, 4, 0), (3600, 16, 1), (100, 4, 2), (14400, 15, 3), (777, 8, 4), (4097, 7, 5),
+                                      (2049, 4, 6), (17, 4, 7), (1009, 10, 8), (19000, 16, 9)])
 def test_l1_injected_confidences(N, g, seed):
     from oracle import searcher_ref as S
     from tstar_amd.interface_searcher import _DeviceState
