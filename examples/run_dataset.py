@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--nframes", type=int, default=600)
     ap.add_argument("--search-nframes", type=int, default=8)
     ap.add_argument("--grid", type=int, default=4)
-    ap.add_argument("--lockstep", type=int, default=4)
+    ap.add_argument("--lockstep", type=int, default=16)
     ap.add_argument("--seed", type=int, default=2025)
     ap.add_argument("--out", default="./output/tstar_results.json")
     args = ap.parse_args()
