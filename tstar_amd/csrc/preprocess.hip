@@ -211,11 +211,21 @@ static int get_lintab(int src, int dst, const int4** out) {
 struct Rgb { int r, g, b; };
 __device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
+// unaligned wide load (the hardware serves it; one instruction instead of six byte loads)
+struct __attribute__((packed)) PackedU64 { uint64_t v; };
+
 struct SrcRGB {
     const uint8_t* p; int W, H;
     __device__ __forceinline__ Rgb at(int x, int y) const {
         const uint8_t* q = p + ((size_t)y * W + x) * 3;
         return Rgb{q[0], q[1], q[2]};
+    }
+    // pixels x and x + 1 of row y from ONE 8-byte load; caller guarantees x <= W - 3 (the load stays inside the row)
+    static constexpr bool kWidePair = true;
+    __device__ __forceinline__ void pair(int x, int y, Rgb& a, Rgb& b) const {
+        const uint64_t v = reinterpret_cast<const PackedU64*>(p + ((size_t)y * W + x) * 3)->v;
+        a = Rgb{(int)(v & 0xFF), (int)((v >> 8) & 0xFF), (int)((v >> 16) & 0xFF)};
+        b = Rgb{(int)((v >> 24) & 0xFF), (int)((v >> 32) & 0xFF), (int)((v >> 40) & 0xFF)};
     }
     static __device__ __forceinline__ size_t frame_bytes(int H, int W) { return (size_t)H * W * 3; }
 };
@@ -228,13 +238,21 @@ struct SrcNV12 {
         return Rgb{clip255((298 * c + 409 * e + 128) >> 8), clip255((298 * c - 100 * d - 208 * e + 128) >> 8),
                    clip255((298 * c + 516 * d + 128) >> 8)};
     }
+    static constexpr bool kWidePair = false;     // measured: a two-pixel form (u16 luma + u32 chroma) is slower here
+    __device__ __forceinline__ void pair(int, int, Rgb&, Rgb&) const {}
     static __device__ __forceinline__ size_t frame_bytes(int H, int W) { return (size_t)H * W * 3 / 2; }
 };
 
 // one bilinear sample (all three channels) at output taps tx, ty
 template <class SRC>
 __device__ __forceinline__ Rgb lin_sample(const SRC& im, const int4 tx, const int4 ty) {
-    const Rgb a = im.at(tx.x, ty.x), b = im.at(tx.y, ty.x), c = im.at(tx.x, ty.y), d = im.at(tx.y, ty.y);
+    Rgb a, b, c, d;
+    if (SRC::kWidePair && tx.y == tx.x + 1 && tx.x <= im.W - 3) {     // two adjacent source columns, away from the edge
+        im.pair(tx.x, ty.x, a, b);
+        im.pair(tx.x, ty.y, c, d);
+    } else {
+        a = im.at(tx.x, ty.x); b = im.at(tx.y, ty.x); c = im.at(tx.x, ty.y); d = im.at(tx.y, ty.y);
+    }
     auto mix = [&](int p00, int p01, int p10, int p11) {
         const int h0 = p00 * tx.z + p01 * tx.w;
         const int h1 = p10 * tx.z + p11 * tx.w;
