@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tstar_amd import _lib
 lib=_lib.load(); s=torch.cuda.current_stream().cuda_stream
