@@ -117,3 +117,23 @@ def test_odd_resolution_and_non_unit_fps_store():
     grid = s._device_grid(secs0).cpu().numpy()
     assert np.array_equal(grid, R.frames_to_grid([frames[i] for i in secs0], 2, 2))
     assert np.array_equal(fr, frames[[int(t) for t in ts]])
+
+
+def test_create_image_grid_reference_method():
+    """TStarSearcher.create_image_grid (interface_searcher.py:171-188): host frames -> 200x95 cells tiled row-major;
+    same bilinear as the oracle, and the reference's error for a wrong frame count."""
+    from oracle import resize_ref as R
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_video
+    h = OWLInterface(synthetic_seed=0, max_batch=2)
+    s = TStarSearcher(synthetic_video(40, seed=2), h, ["couch"], ["tv"], search_nframes=4, image_grid_shape=(2, 3),
+                      search_budget=1.0, rng=np.random.RandomState(0), keep_visual_history=False)
+    rs = np.random.RandomState(5)
+    frames = [rs.randint(0, 256, (380, 800, 3)).astype(np.uint8) for _ in range(6)]
+    grid = s.create_image_grid(frames, 2, 3)
+    small = [R.cv_bilinear_resize(f, 200, 95) for f in frames]
+    ref = np.vstack([np.hstack(small[r * 3:(r + 1) * 3]) for r in range(2)])
+    assert grid.shape == (190, 600, 3) and np.array_equal(grid, ref)
+    with pytest.raises(ValueError, match="Frame count does not match grid dimensions"):
+        s.create_image_grid(frames[:5], 2, 3)

@@ -256,9 +256,26 @@ class TStarSearcher:
         secs = [min(last, max(0, int(round(float(i) / self.raw_fps * self.fps)))) for i in frame_indices]
         return frame_indices, self.store.host_frames(secs)
 
-    def create_image_grid(self, frames: List[np.ndarray], rows: int, cols: int):
-        raise NotImplementedError("grid images are built on the device by tstar_frames_to_grid; "
-                                  "use TStarSearcher._device_grid(secs)")
+    def create_image_grid(self, frames: List[np.ndarray], rows: int, cols: int) -> np.ndarray:
+        """(:171-188) host frames (equal-size HxWx3 uint8) -> each resized to 200x95 and tiled row-major into one
+        [95 rows, 200 cols, 3] image.  ``search()`` itself never calls this (its grid is built straight from the
+        resident frame store by ``_device_grid``); kept for callers of the reference method: the frames make a round
+        trip through the device so the resize is the same kernel."""
+        import torch
+        if len(frames) != rows * cols:
+            raise ValueError("Frame count does not match grid dimensions")      # :183-184
+        st = np.ascontiguousarray(np.stack([np.asarray(f, dtype=np.uint8) for f in frames]))
+        if st.ndim != 4 or st.shape[3] != 3:
+            raise ValueError("create_image_grid expects HxWx3 uint8 frames of one size")
+        n, H, Wd, _ = st.shape
+        dev = self.store.frames.device
+        d = torch.from_numpy(st).to(dev)
+        out = torch.empty((n, CELL_H, CELL_W, 3), dtype=torch.uint8, device=dev)
+        idx = torch.arange(n, dtype=torch.int32, device=dev)
+        _lib.check(self._state.lib.tstar_frames_resize(d.data_ptr(), n, H, Wd, idx.data_ptr(), n, CELL_W, CELL_H,
+                                                       out.data_ptr(), 0, _lib.stream_ptr()), "tstar_frames_resize")
+        grid = out.view(rows, cols, CELL_H, CELL_W, 3).permute(0, 2, 1, 3, 4).reshape(rows * CELL_H, cols * CELL_W, 3)
+        return grid.cpu().numpy()
 
     def _device_grid(self, secs):
         import torch
