@@ -444,3 +444,45 @@ def test_query_sets_are_independent():
     from tstar_amd import _lib
     with pytest.raises(_lib.TStarHipError, match="no queries installed"):
         h.score_batch(img, 1, 1, image_sets=[1, 7])
+
+
+def test_reference_style_manual_loop_equals_search():
+    """Drive the searcher the way the reference's own ``search()`` body does (:444-491) -- sample_frames, one grid
+    detector pass, the PUBLIC ``update_frame_distribution`` with host confidence maps, then ``verify_and_remove_target``
+    frame by frame -- and compare with ``search()`` (device confidences, speculative batched verification) on an
+    identically seeded searcher: same sampled seconds, same histories, same keyframes."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_video
+    h = OWLInterface(synthetic_seed=0, max_batch=8)
+    store = synthetic_video(600, seed=4)
+
+    def make():
+        return TStarSearcher(store, h, ["couch"], ["tv", "chair"], search_nframes=4, image_grid_shape=(3, 3),
+                             search_budget=0.1, confidence_threshold=0.6, rng=np.random.RandomState(7),
+                             keep_visual_history=False)
+
+    a = make()
+    frames_a, ts_a = a.search()
+
+    b = make()
+    rows, cols = b.image_grid_shape
+    while b.remaining_targets and b.search_budget > 0:
+        secs = b.sample_frames(rows * cols)
+        b.search_budget -= rows * cols
+        grid = b._device_grid(secs)
+        res = h.score_batch(grid.unsqueeze(0), rows, cols)
+        conf_maps = res.cell_conf.cpu().numpy().reshape(1, rows, cols)
+        masks = res.cell_mask[0].cpu().numpy().astype(np.uint32)
+        det_maps = [[b._names_from_mask(int(m)) for m in masks]]
+        confs, objs = b.update_frame_distribution(secs, conf_maps, det_maps)
+        assert len(confs) == len(secs) and objs == det_maps[0][:len(secs)]
+        for sec, names in zip(secs, objs):
+            b.verify_and_remove_target(sec, names, b.confidence_threshold)
+    frames_b, ts_b = b.pop_frames(b.video_path, b.search_nframes)
+    assert list(ts_a) == list(ts_b)
+    assert np.array_equal(frames_a, frames_b)
+    assert len(a.Score_history) == len(b.Score_history) and a.Score_history == b.Score_history
+    assert a.non_visiting_history == b.non_visiting_history and a.P_history == b.P_history
+    assert np.array_equal(a.score_distribution, b.score_distribution)
+    assert sorted(a.remaining_targets) == sorted(b.remaining_targets)

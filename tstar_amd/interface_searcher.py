@@ -324,6 +324,21 @@ class TStarSearcher:
         self.store_score_distribution()
         return ctx
 
+    def update_frame_distribution(self, sampled_frame_indices, confidence_maps, detected_objects_maps):
+        """(:276-321) public form over host arrays: cell (i // cols, i % cols) of ``confidence_maps[0]`` belongs to the
+        i-th sampled second; write-back, top-quartile window spread, spline distribution, history -- all on the
+        device state (``search()`` feeds the device confidences directly through ``_update_from_device``)."""
+        import torch
+        confidence_map = np.asarray(confidence_maps[0], dtype=np.float64)
+        detected_objects_map = detected_objects_maps[0]
+        _, grid_cols = self.image_grid_shape
+        secs = [int(s) for s in sampled_frame_indices]
+        frame_confidences = [confidence_map[i // grid_cols, i % grid_cols] for i in range(len(secs))]
+        frame_detected_objects = [detected_objects_map[i] for i in range(len(secs))]
+        d_conf = torch.tensor(frame_confidences, dtype=torch.float64, device=self.store.frames.device)
+        self._update_from_device(secs, d_conf)
+        return frame_confidences, frame_detected_objects
+
     # ---- sampling --------------------------------------------------------------------------------
     def sample_frames(self, num_samples: int):
         """(:324-363) returns (seconds in draw order, device grid-ready frame indices).  The resized
@@ -398,6 +413,38 @@ class TStarSearcher:
                         break
         if upd_s:
             self._state.set_scores(upd_s, upd_v)
+
+    def verify_and_remove_target(self, frame_sec: int, detected_objects: List[str], confidence_threshold: float) -> bool:
+        """(:382-420) one frame: if a remaining target is among ``detected_objects``, re-score the frame alone at
+        600x285, overwrite its score, and drop the target when it is confirmed above the threshold.  ``search()``
+        batches these calls per iteration (``_verify_launch`` / ``_verify_replay``) with identical results."""
+        for target in list(self.remaining_targets):
+            if target in detected_objects:
+                d_frame = self._device_verify_frames([int(frame_sec)])
+                if self._fast:
+                    res = self.heuristic.score_batch(d_frame, 1, 1)
+                    single_conf = float(res.cell_conf[0, 0].item())
+                    single_names = self._names_from_mask(int(res.cell_mask[0, 0].item()) & 0xFFFFFFFF)
+                    det = self.heuristic._detections_from(res, 0) if self.keep_visual_history else None
+                else:
+                    conf_map, det_map = self.score_image_grids([d_frame[0].cpu().numpy()], (1, 1))
+                    single_conf, single_names = conf_map[0, 0, 0], det_map[0][0]
+                    det = None
+                self._state.set_scores([int(frame_sec)], [single_conf])
+                self.frames_scored += 1
+                self.detector_calls += 1
+                self.device_images_scored += 1
+                if self.keep_visual_history:
+                    frame = d_frame[0].cpu().numpy()
+                    dets = [det] if det is not None else self.heuristic.detections_inbatch
+                    self.image_grid_iters.append([frame])
+                    self.detect_annotot_iters.append(self.heuristic.bbox_visualization([frame], dets))
+                    self.detect_bbox_iters.append(dets)
+                if target in single_names and single_conf > confidence_threshold:
+                    self.remaining_targets.remove(target)
+                    print(f"Found target '{target}' in frame {int(frame_sec * self.raw_fps / self.fps)}, score {single_conf:.2f}")
+                    return True
+        return False
 
     def _verify_generic(self, secs, names_per_frame):
         for sec, names in zip(secs, names_per_frame):
