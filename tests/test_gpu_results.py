@@ -49,3 +49,19 @@ def test_result_wire_format(tmp_path):
     assert back[0]["keyframe_distribution"] == r["keyframe_distribution"]
     sel = topk_seconds(back[0]["keyframe_distribution"], 8)
     assert len(sel) == 8 and list(sel) == sorted(sel)
+
+
+def test_owl_inference_from_image_file(tmp_path):
+    """OWLInterface.inference (interface_heuristic.py:217-230): a file on disk gives the detections of the same pixels
+    passed through inference_detector."""
+    from PIL import Image
+    from tstar_amd.interface_heuristic import OWLInterface
+    h = OWLInterface(synthetic_seed=0, max_batch=2)
+    h.reparameterize_object_list(["couch"], ["tv"])
+    img = np.random.RandomState(3).randint(0, 256, (285, 600, 3)).astype(np.uint8)
+    path = tmp_path / "frame.png"
+    Image.fromarray(img).save(path)
+    a = h.inference(str(path))
+    b = h.inference_detector([img])[0]
+    assert np.array_equal(a.xyxy, b.xyxy) and np.array_equal(a.confidence, b.confidence)
+    assert np.array_equal(a.class_id, b.class_id) and len(a.confidence) > 0

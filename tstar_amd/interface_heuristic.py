@@ -122,6 +122,13 @@ class OWLInterface(HeuristicInterface):
         self.detections_inbatch = dets
         return dets
 
+    def inference(self, image_path, use_amp: bool = False) -> Detections:
+        """(:217-230) detector on an image FILE (decoded with Pillow, RGB) against the current ``texts``."""
+        from PIL import Image
+        with Image.open(image_path) as im:
+            image = np.asarray(im.convert("RGB"), dtype=np.uint8)
+        return self.inference_detector([image], use_amp=use_amp)[0]
+
     def bbox_visualization(self, images, detections_inbatch):
         out = []
         for image, det in zip(images, detections_inbatch):
