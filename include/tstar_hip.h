@@ -190,6 +190,11 @@ int tstar_topk_seconds(const double* d_P, int N, int clip_start, int clip_end, i
 int tstar_ssim_pairwise(const uint8_t* d_gt, int G, const uint8_t* d_pred, int P, int H, int W,
                         const float* h_window, double* d_out, void* stream);
 
+/* Replaces OWLInterface.bbox_visualization (interface_heuristic.py:259-267) for images that are already on the
+ * device: paints the 1-px box of every kept detection (score > 0.005) of image b -- d_boxes_xyxy [B,576,4] and
+ * d_scores [B,576] as written by tstar_owl_score -- onto d_images u8 [B,H,W,3] in place. */
+int tstar_draw_boxes(uint8_t* d_images, int B, int H, int W, const float* d_boxes_xyxy, const float* d_scores, void* stream);
+
 /* ------------------------------------------------------------------ kernel-level diagnostics
  * (used by tests/ and bench.py to check and time individual kernels) */
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual); act: 0 none, 1 quick-gelu, 2 gelu(erf) */

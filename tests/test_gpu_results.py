@@ -65,3 +65,29 @@ def test_owl_inference_from_image_file(tmp_path):
     b = h.inference_detector([img])[0]
     assert np.array_equal(a.xyxy, b.xyxy) and np.array_equal(a.confidence, b.confidence)
     assert np.array_equal(a.class_id, b.class_id) and len(a.confidence) > 0
+
+
+def test_device_box_painter_equals_host_painter():
+    """The searcher's visual history paints boxes on the device (tstar_draw_boxes) and copies frames and detections
+    to the host once per batch; the result must equal the host painter (OWLInterface.bbox_visualization) applied to the
+    un-annotated frames with the same detections."""
+    import torch
+    from tstar_amd.interface_heuristic import OWLInterface
+    h = OWLInterface(synthetic_seed=0, max_batch=4)
+    h.reparameterize_object_list(["couch"], ["tv", "chair"])
+    rs = np.random.RandomState(8)
+    frames = rs.randint(0, 256, (3, 285, 600, 3)).astype(np.uint8)
+    d = torch.from_numpy(frames).cuda()
+    res = h.score_batch(d, 1, 1)
+    imgs, dets = h.annotated_batch(d, res)
+    assert imgs.shape == frames.shape and len(dets) == 3
+    for k in range(3):
+        ref_det = h._detections_from(res, k)
+        assert np.array_equal(dets[k].xyxy, ref_det.xyxy) and np.array_equal(dets[k].class_id, ref_det.class_id)
+        want = h.bbox_visualization([frames[k].copy()], [ref_det])[0]
+        assert np.array_equal(imgs[k], want)
+        assert (imgs[k] != frames[k]).any()                 # something was painted
+    # a sub-range of a batch result
+    d2 = torch.from_numpy(frames[1:3].copy()).cuda()
+    imgs2, dets2 = h.annotated_batch(d2, res, 1, 2)
+    assert np.array_equal(imgs2, imgs[1:3]) and np.array_equal(dets2[1].confidence, dets[2].confidence)

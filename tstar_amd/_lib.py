@@ -54,6 +54,7 @@ SIGNATURES = {
     "tstar_gemm_bf16w": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tstar_gemm_f32_split": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tstar_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "tstar_draw_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "tstar_attention_split": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tstar_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tstar_prof_enable": (_i, [_i]),

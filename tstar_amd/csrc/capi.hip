@@ -539,6 +539,11 @@ int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int head
     return attention_f32(d_qkv, d_out, B, T, heads, mode, d_key_mask, (hipStream_t)stream);
 }
 
+int tstar_draw_boxes(uint8_t* d_images, int B, int H, int W, const float* d_boxes_xyxy, const float* d_scores, void* stream) {
+    TSTAR_REQUIRE(d_images && d_boxes_xyxy && d_scores, "tstar_draw_boxes: null argument");
+    return draw_boxes(d_images, B, H, W, d_boxes_xyxy, d_scores, V_NP, 0.005f, (hipStream_t)stream);
+}
+
 int tstar_attention_split(const float* d_qkv, float* d_out, int B, int T, int heads, void* stream) {
     TSTAR_REQUIRE(d_qkv && d_out, "tstar_attention_split: null argument");
     return attention_split(d_qkv, d_out, B, T, heads, (hipStream_t)stream);

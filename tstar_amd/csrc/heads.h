@@ -30,6 +30,9 @@ int cell_reduce(const float* scores, const int* labels, const float* xyxy, const
                 int img_w, int img_h, int grows, int gcols, float thr, double* cell_conf, uint32_t* cell_mask,
                 int* n_kept, hipStream_t s);
 
+// paint the kept detections' boxes (score > thr) on u8 images [B,H,W,3] in place; xyxy [B,np,4], scores [B,np]
+int draw_boxes(uint8_t* images, int B, int H, int W, const float* xyxy, const float* scores, int np, float thr, hipStream_t s);
+
 // ---- preprocess.hip ----
 // Pillow-compatible fixed-point resampling tables for one axis (host side).
 struct ResampleTable {

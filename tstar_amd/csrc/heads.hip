@@ -183,4 +183,29 @@ int cell_reduce(const float* scores, const int* labels, const float* xyxy, const
     return TSTAR_OK;
 }
 
+// 1-px rectangles of every kept detection (score > thr) painted in place on u8 images [B,H,W,3]: the device form of
+// OWLInterface.bbox_visualization (interface_heuristic.py:259-267) for the searcher's visual history.  Corner
+// coordinates are rounded half-to-even and clamped exactly like the host painter (tstar_amd.interface_heuristic.
+// draw_boxes); one colour, so the painting order does not matter.
+__global__ __launch_bounds__(64) void draw_boxes_kernel(uint8_t* __restrict__ images, int H, int W, const float* __restrict__ xyxy,
+                                                        const float* __restrict__ scores, int np, float thr) {
+    const int p = blockIdx.x, b = blockIdx.y;
+    if (!(scores[(size_t)b * np + p] > thr)) return;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(xyxy + ((size_t)b * np + p) * 4);
+    auto pix = [](float v, int hi) { const double r = rint((double)v); return (int)(r < 0.0 ? 0.0 : (r > (double)hi ? (double)hi : r)); };
+    const int xa = pix(bb[0], W - 1), ya = pix(bb[1], H - 1), xb = pix(bb[2], W - 1), yb = pix(bb[3], H - 1);
+    if (xb < xa || yb < ya) return;
+    uint8_t* img = images + (size_t)b * H * W * 3;
+    auto put = [&](int x, int y) { uint8_t* q = img + ((size_t)y * W + x) * 3; q[0] = 255; q[1] = 64; q[2] = 64; };
+    for (int x = xa + (int)threadIdx.x; x <= xb; x += 64) { put(x, ya); put(x, yb); }
+    for (int y = ya + (int)threadIdx.x; y <= yb; y += 64) { put(xa, y); put(xb, y); }
+}
+
+int draw_boxes(uint8_t* images, int B, int H, int W, const float* xyxy, const float* scores, int np, float thr, hipStream_t s) {
+    TSTAR_REQUIRE(B > 0 && H > 0 && W > 0 && np > 0, "draw_boxes: empty problem");
+    hipLaunchKernelGGL(draw_boxes_kernel, dim3(np, B), dim3(64), 0, s, images, H, W, xyxy, scores, np, thr);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
 }  // namespace tstar

@@ -31,6 +31,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import weights as W
+from . import _lib
 from .tokenizer import encode_queries
 
 
@@ -164,6 +165,27 @@ class OWLInterface(HeuristicInterface):
         self.scorer.set_queries(ids, am, [float(o2w.get(t[0], 0.5)) for t in texts], slot=int(slot))
         return texts
 
+    def annotated_batch(self, d_images, r, start: int = 0, count: Optional[int] = None):
+        """Device form of ``bbox_visualization`` + ``Detections`` for images that are already on the device (the
+        searcher's visual history): paints the kept boxes of ``r`` (images ``start .. start+count`` of a
+        ``score_batch`` result) onto ``d_images`` u8 [count,H,W,3] IN PLACE, then brings images and detections to the
+        host with one copy each.  Returns (images uint8 [count,H,W,3], [Detections] * count)."""
+        count = int(d_images.shape[0]) if count is None else int(count)
+        if not d_images.is_contiguous() or d_images.shape[0] != count:
+            raise ValueError("annotated_batch: d_images must be a contiguous [count,H,W,3] uint8 device tensor")
+        boxes = r.boxes[start:start + count].contiguous()
+        scores = r.scores[start:start + count].contiguous()
+        lib = _lib.load()
+        _lib.check(lib.tstar_draw_boxes(d_images.data_ptr(), count, int(d_images.shape[1]), int(d_images.shape[2]),
+                                        boxes.data_ptr(), scores.data_ptr(), _lib.stream_ptr()), "tstar_draw_boxes")
+        imgs = d_images.cpu().numpy()
+        s, bx, lab = scores.cpu().numpy(), boxes.cpu().numpy(), r.labels[start:start + count].cpu().numpy()
+        dets = []
+        for k in range(count):
+            keep = s[k] > np.float32(0.005)
+            dets.append(Detections(xyxy=bx[k][keep], confidence=s[k][keep], class_id=lab[k][keep].astype(np.int64)))
+        return imgs, dets
+
     def _detections_from(self, r, b: int) -> Detections:
         s = r.scores[b].cpu().numpy()
         keep = s > np.float32(0.005)
@@ -175,9 +197,11 @@ def draw_boxes(image: np.ndarray, det: Detections, color=(255, 64, 64)) -> np.nd
     """1-px rectangles painted IN PLACE on ``image`` (the reference's supervision BoxAnnotator also
     paints on the array it is given, Appendix B.14) and returned."""
     H, Wd = image.shape[:2]
-    for x0, y0, x1, y1 in np.asarray(det.xyxy, dtype=np.float64).reshape(-1, 4):
-        xa, xb = int(max(0, min(Wd - 1, round(x0)))), int(max(0, min(Wd - 1, round(x1))))
-        ya, yb = int(max(0, min(H - 1, round(y0)))), int(max(0, min(H - 1, round(y1))))
+    b = np.asarray(det.xyxy, dtype=np.float64).reshape(-1, 4)
+    # round half to even (Python round / np.rint / the device painter's rint), clamp to the image
+    xs = np.clip(np.rint(b[:, [0, 2]]), 0, Wd - 1).astype(np.int64)
+    ys = np.clip(np.rint(b[:, [1, 3]]), 0, H - 1).astype(np.int64)
+    for (xa, xb), (ya, yb) in zip(xs.tolist(), ys.tolist()):
         if xb < xa or yb < ya:
             continue
         image[ya, xa:xb + 1] = color

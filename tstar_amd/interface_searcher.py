@@ -391,6 +391,7 @@ class TStarSearcher:
         searcher is row ``j`` of vconf/vmask (and image ``res_offset + j`` of ``res`` / ``vframes``)."""
         slot = {i: j for j, i in enumerate(cands)}
         upd_s, upd_v = [], []
+        hist = None            # (annotated frames, detections) of this searcher's candidates, fetched on first use
         for i, (sec, names) in enumerate(zip(secs, names_per_frame)):
             for target in list(self.remaining_targets):
                 if target in names:
@@ -402,10 +403,12 @@ class TStarSearcher:
                     self.frames_scored += 1
                     self.detector_calls += 1
                     if self.keep_visual_history and res is not None:
-                        frame = vframes[res_offset + j].cpu().numpy()
-                        det = self.heuristic._detections_from(res, res_offset + j)
-                        self.image_grid_iters.append([frame])
-                        self.detect_annotot_iters.append(self.heuristic.bbox_visualization([frame], [det]))
+                        if hist is None:       # boxes painted on the device, one copy for all candidates
+                            hist = self.heuristic.annotated_batch(vframes[res_offset:res_offset + len(cands)], res,
+                                                                  res_offset, len(cands))
+                        frame, det = hist[0][j], hist[1][j]
+                        self.image_grid_iters.append([frame])          # the annotated array, aliased like the
+                        self.detect_annotot_iters.append([frame])      # reference's in-place annotation (B.14)
                         self.detect_bbox_iters.append([det])
                     if target in single_names and single_conf > self.confidence_threshold:
                         self.remaining_targets.remove(target)
@@ -483,12 +486,11 @@ class TStarSearcher:
                 masks = res.cell_mask[0].cpu().numpy().astype(np.uint32)
                 names_per_frame = [self._names_from_mask(int(m)) for m in masks[:len(secs)]]
                 if self.keep_visual_history:
-                    g = grid.cpu().numpy()
-                    det = self.heuristic._detections_from(res, 0)
-                    self.heuristic.detections_inbatch = [det]
-                    self.image_grid_iters.append([g])
-                    self.detect_annotot_iters.append(self.heuristic.bbox_visualization([g], [det]))
-                    self.detect_bbox_iters.append([det])
+                    imgs, dets = self.heuristic.annotated_batch(grid.unsqueeze(0), res, 0, 1)
+                    self.heuristic.detections_inbatch = dets
+                    self.image_grid_iters.append([imgs[0]])
+                    self.detect_annotot_iters.append([imgs[0]])
+                    self.detect_bbox_iters.append(dets)
             else:
                 g = grid.cpu().numpy()
                 conf_maps, name_maps = self.score_image_grids([g], self.image_grid_shape)

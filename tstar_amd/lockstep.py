@@ -66,11 +66,10 @@ def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray
             names = [s._names_from_mask(int(m)) for m in masks[i][:len(secs_l[i])]]
             names_l.append(names)
             if s.keep_visual_history:
-                g = grids[i].cpu().numpy()
-                det = h._detections_from(res, i)
-                s.image_grid_iters.append([g])
-                s.detect_annotot_iters.append(h.bbox_visualization([g], [det]))
-                s.detect_bbox_iters.append([det])
+                imgs, dets = h.annotated_batch(grids[i].unsqueeze(0), res, i, 1)
+                s.image_grid_iters.append([imgs[0]])
+                s.detect_annotot_iters.append([imgs[0]])
+                s.detect_bbox_iters.append(dets)
             s.frames_scored += n
             s.detector_calls += 1
             fits.append(s._state.apply_grid(secs_l[i], res.cell_conf[i]))
