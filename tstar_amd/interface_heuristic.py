@@ -114,7 +114,7 @@ class OWLInterface(HeuristicInterface):
 
     def inference_detector(self, images, **kwargs) -> List[Detections]:
         import torch
-        img = np.ascontiguousarray(np.asarray(images[0], dtype=np.uint8))     # only image 0, as the reference
+        img = np.array(images[0], dtype=np.uint8, order="C")                  # only image 0, as the reference (own copy)
         if img.ndim != 3 or img.shape[2] != 3:
             raise ValueError("inference_detector expects HxWx3 uint8 RGB images")
         d_img = torch.from_numpy(img).cuda().unsqueeze(0)
