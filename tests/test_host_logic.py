@@ -214,3 +214,40 @@ def test_checkpoint_directory_round_trip(tmp_path):
     assert np.array_equal(wt["text_proj"], ref["owlvit.text_projection.weight"])
     assert np.array_equal(wv["box_bias"], m.box_bias.numpy())       # restated buffer == HF's
     assert W.find_pretrained(str(tmp_path / "missing")) is None
+
+
+def test_open_video_through_a_decord_like_reader(monkeypatch):
+    """File paths are decoded once through decord (interface_searcher.py:157-169 reopens it per call): with a stub
+    reader, the store holds raw frame int(sec * raw_fps) for every logical second and keeps raw fps / frame count."""
+    import types
+    from tstar_amd import video
+
+    class _Batch:
+        def __init__(self, a):
+            self._a = a
+
+        def asnumpy(self):
+            return self._a
+
+    class VideoReader:
+        def __init__(self, path, ctx=None):
+            assert path == "/data/clip.mp4"
+
+        def get_avg_fps(self):
+            return 29.97
+
+        def __len__(self):
+            return 305                       # 10 whole seconds and a bit
+
+        def get_batch(self, idx):
+            return _Batch(np.stack([np.full((6, 8, 3), i % 251, np.uint8) for i in idx]))
+
+    stub = types.ModuleType("decord")
+    stub.VideoReader = VideoReader
+    stub.cpu = lambda i: None
+    monkeypatch.setitem(sys.modules, "decord", stub)
+    st = video.open_video("/data/clip.mp4", device="cpu")
+    assert st.num_seconds == 10 and st.raw_fps == 29.97 and st.raw_total_frames == 305
+    want = [int(s * 29.97) % 251 for s in range(10)]
+    assert [int(st.frames[s, 0, 0, 0]) for s in range(10)] == want
+    assert st.shape == (10, 6, 8, 3)
