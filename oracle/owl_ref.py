@@ -24,7 +24,6 @@ returned by ``tstar_amd.weights.unpack_blob``.
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, Tuple
 
 import numpy as np

@@ -1,6 +1,5 @@
 """Kernel-level parity: each HIP kernel (through the C ABI) vs a plain torch fp32 CPU
 statement of the same op."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -1,6 +1,5 @@
 """CPU: the searcher oracle (oracle/searcher_ref.py) against golden vectors produced by the REFERENCE
 itself (tests/golden/make_goldens.py imports /root/reference/TStar/interface_searcher.py unmodified)."""
-import glob
 import os
 
 import numpy as np

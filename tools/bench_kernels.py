@@ -1,5 +1,5 @@
 """Micro-benchmarks of the individual HIP kernels (GPU box only)."""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tstar_amd import _lib

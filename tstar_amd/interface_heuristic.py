@@ -26,7 +26,7 @@ still works through ``inference_detector``): ``set_class_weights``, ``score_batc
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional
 
 import numpy as np
 

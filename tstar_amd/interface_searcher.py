@@ -20,7 +20,7 @@ iteration, budget overshoot.  ``search_with_visualization`` is ``search`` (:493-
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 from scipy.interpolate import UnivariateSpline      # FITPACK fit on the host, as the reference (:265)

@@ -13,7 +13,6 @@ from __future__ import annotations
 
 from typing import Callable, List, Sequence
 
-import numpy as np
 
 
 def shard_items(n_items: int, world: int, rank: int) -> List[int]:

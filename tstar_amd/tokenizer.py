@@ -13,7 +13,7 @@ each query padded to 16 tokens, ``[BOS=49406, tokens.., EOS=49407, 0..]``.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 
