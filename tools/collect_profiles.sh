@@ -12,8 +12,9 @@ export TMPDIR=/tmp
 cd /tmp
 PY="python $ROOT/bench.py"
 
-# 1. the bench line itself (default flags) and the secondary workloads
-$PY --steps 8 --warmup 1 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
+# 1. the secondary workloads (the bench line itself runs last, after the counter passes, so that its
+#    roofline.traffic field is this collection's figure)
+: > "$OUT/bench.err"
 $PY --steps 16 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --weights f32_split --no-cpu-baseline > "$OUT/${TAG}_bench_f32_split.json" 2>> "$OUT/bench.err"
@@ -45,7 +46,12 @@ python $ROOT/tools/rocpd_pmc.py "$F" "$W" > "$OUT/${TAG}_pmc_fetch_write_by_kern
 python $ROOT/tools/rocpd_pmc.py "$M" "$M2" > "$OUT/${TAG}_pmc_mfma_by_kernel.md"
 python $ROOT/tools/rocpd_mfma.py "$M" > "$OUT/${TAG}_pmc_mfma_utilisation.md"
 
-# 4. kernel microbenchmarks
+# 4. the bench line (default flags), reading the traffic figure just collected
+cp "$OUT/${TAG}_pmc_gemm_traffic.json" "$ROOT/profiles/${TAG}_pmc_gemm_traffic.json"
+$PY > "$OUT/${TAG}_bench.json" 2>> "$OUT/bench.err"
+
+# 5. kernel microbenchmarks
 python $ROOT/tools/bench_gemm_cfg.py > "$OUT/${TAG}_gemm_tile_configs.log" 2>&1
 python $ROOT/tools/bench_kernels.py > "$OUT/${TAG}_kernel_microbench.log" 2>&1
+python $ROOT/tools/bench_ingest.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_ingest_bandwidth.log"
 ls -la "$OUT"
