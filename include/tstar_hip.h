@@ -81,19 +81,20 @@ int tstar_owl_destroy(tstar_owl* h);
 /* Replaces the text half of processor(...)+model(...) that the reference recomputes on every
  * detector call (interface_heuristic.py:234,239 -> HF modeling_owlvit.py:945-958, 631-663):
  * runs the CLIP text tower once for Q queries (ids/mask int32 [Q,16]) and keeps the
- * L2-normalised query embeddings resident.  h_class_weight [Q] = object2weight of each
- * query's name (interface_searcher.py:88-91,136).  `query_set` (0..TSTAR_OWL_MAX_SETS-1) is the slot the queries are stored
+ * L2-normalised query embeddings resident.  h_class_weight float64 [Q] = object2weight of each
+ * query's name (interface_searcher.py:88-91,136; Python floats in the reference, and the
+ * confidence score * weight is formed in float64 as under the reference's pinned numpy 1.26).  `query_set` (0..TSTAR_OWL_MAX_SETS-1) is the slot the queries are stored
  * in: several (video, question) items can be resident at once and every image of a tstar_owl_score call
  * names the slot it is scored against (the reference keeps exactly one query set, = slot 0).
  * Synchronises `stream`. */
 int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_input_ids, const int32_t* h_attention_mask,
-                          const float* h_class_weight, int Q, void* stream);
+                          const double* h_class_weight, int Q, void* stream);
 /* Same, from precomputed L2-normalised embeddings float32 [Q,512] and query mask u8 [Q]. */
 int tstar_owl_set_query_embeds(tstar_owl* h, int query_set, const float* h_query_embeds, const uint8_t* h_query_mask,
-                               const float* h_class_weight, int Q, void* stream);
+                               const double* h_class_weight, int Q, void* stream);
 /* Replaces only the per-query class weights (TStarSearcher sets object2weight AFTER it has
  * reparameterised the heuristic, interface_searcher.py:87-91). */
-int tstar_owl_set_class_weights(tstar_owl* h, int query_set, const float* h_class_weight, int Q, void* stream);
+int tstar_owl_set_class_weights(tstar_owl* h, int query_set, const double* h_class_weight, int Q, void* stream);
 /* Copies the resident (L2-normalised, pre-class-head) query embeddings float32 [Q,512] to the host. */
 int tstar_owl_get_query_embeds(tstar_owl* h, int query_set, float* h_out, int Q, void* stream);
 
@@ -107,7 +108,7 @@ int tstar_owl_get_query_embeds(tstar_owl* h, int query_set, float* h_out, int Q,
  *   d_labels      i32 [B,576]   argmax_q logit
  *   d_boxes_xyxy  f32 [B,576,4] pixels of the passed image
  *   d_cell_conf   f64 [B,rows*cols]  max over detections with score > 0.005 of
- *                                    score * class_weight[label], row-major cells; 0 if none
+ *                                    float64(score) * class_weight[label], row-major cells; 0 if none
  *   d_cell_mask   u32 [B,rows*cols]  bit q set <=> a kept detection with label q fell in the cell
  *   d_n_kept      i32 [B]       number of detections with score > 0.005 (may be NULL)
  *   d_logits      f32 [B,576,Q] raw logits (may be NULL; needs the same Q for every image)
@@ -154,6 +155,13 @@ int tstar_searcher_destroy(tstar_searcher* s);
  * visited frames (ascending) and their scores to the host for the FITPACK fit.  Synchronises. */
 int tstar_searcher_apply_grid(tstar_searcher* s, const int32_t* h_secs, const double* d_conf, int n,
                               int* h_n_visited, int32_t* h_vis_x, double* h_vis_y, void* stream);
+/* update_top_25_with_window alone (interface_searcher.py:215-241) on the device score array: np.percentile(h_conf, 75),
+ * then for every sample with conf >= threshold, in the given order and in place, score[f + o] = max(score[f + o],
+ * score[f] / (|o| + 1)) for |o| <= window.  Synchronises. */
+int tstar_searcher_window_spread(tstar_searcher* s, const int32_t* h_secs, const double* h_conf, int n, int window,
+                                 void* stream);
+/* the visited frames (non_visiting == 0, ascending) and their scores (interface_searcher.py:260-261).  Synchronises. */
+int tstar_searcher_visited(tstar_searcher* s, int* h_n_visited, int32_t* h_vis_x, double* h_vis_y, void* stream);
 /* spline_keyframe_distribution after the fit (interface_searcher.py:266-274): evaluates the
  * B-spline (t, c, k) from scipy's UnivariateSpline at 0..N-1 (FITPACK splev, ext=0), clamps at
  * 1/N, sigmoid, normalises -> P. */
@@ -161,8 +169,10 @@ int tstar_searcher_set_spline(tstar_searcher* s, const double* h_t, const double
 /* sample_frames' weights (interface_searcher.py:345-352) with add = num/N, and the cdf of
  * np.random.choice; *h_fallback = 1 if the unvisited mask was dropped.  Synchronises. */
 int tstar_searcher_sampler_prep(tstar_searcher* s, int num, double add, int* h_fallback, void* stream);
-/* pop_frames' weights (interface_searcher.py:369) and their cdf. */
-int tstar_searcher_pop_prep(tstar_searcher* s, void* stream);
+/* pop_frames' weights (interface_searcher.py:369) and their cdf.  *h_nnz = count_nonzero(p > 0) and *h_sum =
+ * score.sum(): what numpy's choice() validates before drawing ("probabilities contain NaN" when the sum is 0 or NaN,
+ * "Fewer non-zero entries in p than size").  Synchronises. */
+int tstar_searcher_pop_prep(tstar_searcher* s, int* h_nnz, double* h_sum, void* stream);
 /* cdf.searchsorted(x, 'right') for k host-drawn uniforms (the MT19937 stream stays on the host,
  * numpy legacy RandomState.choice).  Synchronises. */
 int tstar_searcher_draw(tstar_searcher* s, const double* h_x, int k, int32_t* h_idx, void* stream);
@@ -173,14 +183,19 @@ int tstar_searcher_set_scores(tstar_searcher* s, const int32_t* h_secs, const do
 /* store_score_distribution (interface_searcher.py:207-213): P, score_distribution and non_visiting_frames
  * copied to h_out f64 [3, N] (in that order) with ONE synchronisation. */
 int tstar_searcher_read_state(tstar_searcher* s, double* h_out, void* stream);
+/* overwrite a state array from the host (the reference's attributes are plain numpy arrays a caller may assign):
+ * 0 score_distribution, 1 non_visiting_frames, 2 P -- e.g. P computed on the host by the reference's own numpy/scipy
+ * calls (bit-identical by construction; tstar_searcher_set_spline is the device-side alternative).  Synchronises. */
+int tstar_searcher_write(tstar_searcher* s, int which, const double* h_in, void* stream);
 /* copy a state array to the host: 0 score, 1 non_visiting, 2 P, 3 sampler p, 4 cdf.  Synchronises. */
 int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* stream);
 
 /* ------------------------------------------------------------------ downstream selection (8f)
  * Replaces the score-based branch of extract_frames (LVHaystackBench/val_qa_results.py:90-110): the k
  * highest-probability seconds of a per-second distribution d_P f64 [N] (device) inside
- * [clip_start, clip_end), returned in ascending order (host int32 [k]); NaN -> 0, all-zero -> uniform;
- * ties resolve to the lowest index.  Synchronises. */
+ * [clip_start, clip_end), returned in ascending order (host int32 [k]); NaN -> 0, all-zero -> uniform; the clip is
+ * normalised in float32 (numpy's pairwise sum, then an f32 divide) BEFORE ranking, as the reference does, so
+ * division-induced ties are reproduced; ties resolve to the lowest index.  Synchronises. */
 int tstar_topk_seconds(const double* d_P, int N, int clip_start, int clip_end, int k, int32_t* h_out, void* stream);
 
 /* Replaces pairwise_ssim / ssim_torch (LVHaystackBench/val_tstar_results.py:48-95): SSIM of every

@@ -10,6 +10,7 @@ No reference source is copied: only inputs and outputs are written.
 
     python tests/golden/make_goldens.py            (takes about 7 minutes on 8 cores)
     python tests/golden/make_goldens.py --only-g10
+    python tests/golden/make_goldens.py --only-g11
 """
 import os
 import sys
@@ -29,12 +30,13 @@ from tstar_amd.video import synthetic_frames_numpy  # noqa: E402
 import golden_util as GU  # noqa: E402
 
 VIDEOS = {}   # path -> dict(n=, fps=, seed=, h=, w=)
+SEEKS = []    # frame indices the code under test asked cv2.VideoCapture for (G11)
 
 
 def install_stubs():
     cv2 = types.ModuleType("cv2")
-    cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_COUNT = 5, 7
-    cv2.COLOR_RGB2BGR = 4
+    cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_COUNT, cv2.CAP_PROP_POS_FRAMES = 5, 7, 1
+    cv2.COLOR_RGB2BGR = cv2.COLOR_BGR2RGB = 4
 
     class VideoCapture:
         def __init__(self, path):
@@ -48,6 +50,14 @@ def install_stubs():
 
         def release(self):
             pass
+
+        def set(self, prop, value):                    # extract_frames seeks by frame index (val_qa_results.py:121)
+            self.pos = int(value)
+            SEEKS.append(int(value))
+
+        def read(self):
+            v = self.v
+            return True, synthetic_frames_numpy([min(self.pos, v["n"] - 1)], v["n"], v["h"], v["w"], v["seed"])[0][:, :, ::-1]
 
     cv2.VideoCapture = VideoCapture
     cv2.resize = lambda img, size: resize_ref.cv_bilinear_resize(np.asarray(img), size[0], size[1])
@@ -343,11 +353,55 @@ def g10_metrics():
     print("g10 done", m.round(4).tolist(), prf)
 
 
+def g11_topk():
+    """Downstream selection of LVHaystackBench/val_qa_results.py (imported unmodified; extract_frames :47-131): the
+    seconds it seeks to for a saved keyframe_distribution -- flat, tied, clipped, zero and NaN cases.  The video is
+    1 fps, so frame index = second.  Where the normalised float32 scores tie, WHICH of the equal seconds numpy's
+    default argsort picks depends on the numpy build / CPU: the golden records the reference's picks on this machine
+    and the normalised value of every pick; tests compare picks where no tie is cut and values otherwise."""
+    g = types.ModuleType("TStar.interface_grounding")
+    g.TStarUniversalGrounder = object                          # imported by the module, never used by extract_frames
+    sys.modules["TStar.interface_grounding"] = g
+    sys.path.insert(0, os.path.join(REF, "LVHaystackBench"))
+    import val_qa_results as Q
+    rs = np.random.RandomState(31)
+    g1 = np.load(os.path.join(OUT, "g1_searcher_case0.npz"))
+    P_real = g1["P_last"]                                      # a real, nearly flat P of a 63-iteration search
+    N = len(P_real)
+    peaky = rs.random_sample(N) ** 8
+    plateau = np.round(rs.random_sample(N) * 6) / 6            # 7 distinct levels: ties everywhere
+    withnan = peaky.copy()
+    withnan[rs.choice(N, 300, replace=False)] = np.nan
+    zeros_in_clip = peaky.copy()
+    zeros_in_clip[500:900] = 0.0
+    cases = [("real_P", P_real, 8, None), ("real_P_clip", P_real, 8, [100.0, 700.9]), ("real_P_k32", P_real, 32, None),
+             ("peaky", peaky, 8, None), ("peaky_clip", peaky, 16, [3000.2, 3599.0]), ("plateau", plateau, 8, None),
+             ("plateau_clip", plateau, 8, [10.0, 50.0]), ("flat", np.full(N, 0.25), 8, None), ("all_zero", np.zeros(N), 8, None),
+             ("nan", withnan, 8, None), ("zero_clip", zeros_in_clip, 8, [500.0, 900.0]), ("short_clip", peaky, 8, [40.0, 45.0])]
+    path = register_video(N, 61)
+    out = {"names": np.array([c[0] for c in cases])}
+    for name, dist, k, clip in cases:
+        del SEEKS[:]
+        item = {} if clip is None else {"vclip_interval_in_video": clip}
+        frames = Q.extract_frames(path, item, frame_distribution=[float(v) for v in dist], num_frames=k, p_fps=1,
+                                  duration_type="video" if clip is None else "clip")
+        out[f"dist_{name}"] = np.asarray(dist, dtype=np.float64)
+        out[f"k_{name}"] = np.int64(k)
+        out[f"clip_{name}"] = np.array([-1.0, -1.0] if clip is None else clip)
+        out[f"secs_{name}"] = np.array(SEEKS, dtype=np.int64)
+        assert len(frames) == len(SEEKS)
+        print("g11", name, SEEKS)
+    np.savez_compressed(os.path.join(OUT, "g11_topk.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     if "--only-g10" in sys.argv:
         g10_metrics()
+        return
+    if "--only-g11" in sys.argv:
+        g11_topk()
         return
     import matplotlib
     matplotlib.use("Agg")
@@ -360,6 +414,7 @@ def main():
             g2_to_g6(TStarSearcher)
             g7_g8_g9(TStarSearcher)
             g10_metrics()
+            g11_topk()
         finally:
             os.chdir(cwd)
 

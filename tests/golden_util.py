@@ -68,3 +68,32 @@ def detector_test_image(seed: int, H: int, W: int) -> np.ndarray:
     low = rs.randint(0, 256, (H // 8 + 1, W // 8 + 1, 3)).astype(np.float32)
     img = np.repeat(np.repeat(low, 8, 0), 8, 1)[:H, :W] + rs.randint(-20, 20, (H, W, 3))
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def g11_cases(golden_dir):
+    """(name, distribution f64 [N], k, clip or None, reference picks) of tests/golden/g11_topk.npz."""
+    import os
+    g = np.load(os.path.join(golden_dir, "g11_topk.npz"), allow_pickle=False)
+    for name in [str(n) for n in g["names"]]:
+        clip = g[f"clip_{name}"]
+        yield name, g[f"dist_{name}"], int(g[f"k_{name}"]), (None if clip[0] < 0 else (float(clip[0]), float(clip[1]))), g[f"secs_{name}"]
+
+
+def check_topk_against_reference(picks, ref_picks, dist_clip, start):
+    """``picks`` vs the reference's recorded picks for one G11 case: identical when the selection does not cut
+    through a run of equal normalised values; otherwise the picked VALUES must be identical (which of the equal
+    seconds numpy's default argsort returns is left to the numpy build / CPU) and ``picks`` must be the
+    lowest-index choice among the tied seconds."""
+    picks, ref_picks = np.asarray(picks, dtype=np.int64), np.asarray(ref_picks, dtype=np.int64)
+    assert len(picks) == len(ref_picks)
+    assert np.all(np.diff(picks) > 0), "ascending, no duplicates"
+    v, rv = dist_clip[picks - start], dist_clip[ref_picks - start]
+    assert np.array_equal(np.sort(v), np.sort(rv)), "picked values differ from the reference's"
+    kth = v.min()
+    cut = np.count_nonzero(dist_clip == kth) > np.count_nonzero(v == kth)          # a tie is cut at the k-th value
+    if not cut:
+        assert np.array_equal(picks, ref_picks)
+    else:
+        tied = np.nonzero(dist_clip == kth)[0] + start
+        assert np.array_equal(picks[v == kth], tied[:np.count_nonzero(v == kth)]), "ties must resolve to the lowest index"
+    return cut

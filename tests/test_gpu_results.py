@@ -20,6 +20,34 @@ def test_topk_matches_oracle(n, k, clip):
     assert np.array_equal(topk_seconds(p, k, clip), S.topk_seconds(p, k, clip))
 
 
+def test_topk_g11_reference_picks(golden_dir):
+    """tstar_topk_seconds vs the reference's own extract_frames picks (golden G11), including the near-flat real P
+    where the float32 division creates ties, and vs the oracle (always identical: same lowest-index tie rule)."""
+    import golden_util as GU
+    from oracle import searcher_ref as S
+    from tstar_amd.results import topk_seconds
+    for name, dist, k, clip, ref in GU.g11_cases(golden_dir):
+        dc, start = S.topk_normalised_clip(dist, clip)
+        got = topk_seconds(dist, k, clip)
+        assert np.array_equal(got, S.topk_seconds(dist, k, clip)), name
+        GU.check_topk_against_reference(got, ref, dc, start)
+
+
+def test_topk_float32_division_ties():
+    """Values that are distinct before ``dist_clip /= dist_clip.sum()`` and equal after it (float32): the kernel
+    must rank the NORMALISED values, as the reference does."""
+    from oracle import searcher_ref as S
+    from tstar_amd.results import topk_seconds
+    rs = np.random.RandomState(3)
+    n = 3600
+    base = 0.5 + rs.random_sample(n) * 1e-7                      # near-flat, like a real P
+    dc, _ = S.topk_normalised_clip(base, None)
+    raw = np.nan_to_num(base.astype(np.float32))
+    assert len(np.unique(dc)) < len(np.unique(raw)) or len(np.unique(dc)) < n // 2
+    for k in (8, 32):
+        assert np.array_equal(topk_seconds(base, k), S.topk_seconds(base, k))
+
+
 def test_topk_degenerate_distributions():
     from oracle import searcher_ref as S
     from tstar_amd.results import topk_seconds

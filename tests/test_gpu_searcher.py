@@ -150,7 +150,7 @@ class _Recorder:
             r = self._orig(d_images, rows, cols)
             self.calls.append(dict(rows=rows, cols=cols, images=d_images.cpu().numpy(),
                                    conf=r.cell_conf.cpu().numpy(), mask=r.cell_mask.cpu().numpy().astype(np.uint32),
-                                   scores=r.scores.cpu().numpy()))
+                                   scores=r.scores.cpu().numpy(), boxes=r.boxes.cpu().numpy(), labels=r.labels.cpu().numpy()))
             return r
         h.score_batch = rec
 
@@ -218,6 +218,108 @@ def test_l2_teacher_forced_end_to_end():
     assert len(s.image_grid_iters) == len(s.detect_annotot_iters) == len(s.detect_bbox_iters)
     assert s.image_grid_iters[0][0].shape == (95 * g, 200 * g, 3)
     assert isinstance(s.P_history[-1], list) and len(s.P_history[-1]) == N
+
+
+def _replay_through_oracle(rec, h, targets, cues, N, g, K, budget, thr, seed):
+    """Teacher-forced replay: the confidences / class masks the HIP pipeline produced (recorded batch by batch) are fed
+    to the oracle searcher (oracle/searcher_ref.SearcherRef, pinned by goldens G1-G6) in the order the reference's
+    loop would have asked for them.  Returns the oracle searcher after ``search()`` and its keyframes."""
+    from oracle import searcher_ref as S
+    names = [t[0] for t in h.texts]
+    calls = iter(rec.calls)
+    pending = {}
+    holder = {}
+
+    def score_fn(kind, secs, rows, cols):
+        if kind == "grid":
+            c = next(calls)
+            assert (c["rows"], c["cols"]) == (rows, cols)
+            nm = [[names[q] for q in range(len(names)) if (int(m) >> q) & 1] for m in c["mask"][0]]
+            # the speculative verification batch of this iteration follows: every sampled frame whose cell lists a
+            # target that is still remaining when the iteration STARTS (tstar_amd _verify_launch)
+            remaining = list(holder["ref"].remaining)
+            cands = [i for i, x in enumerate(nm[:len(secs)]) if any(t in x for t in remaining)]
+            pending.clear()
+            if cands:
+                v = next(calls)
+                assert v["conf"].shape[0] == len(cands)
+                for j, i in enumerate(cands):
+                    pending[secs[i]] = (v["conf"][j, 0], v["mask"][j, 0])
+            return c["conf"][0].reshape(rows, cols), nm
+        conf, m = pending[secs[0]]
+        return np.array([[conf]]), [[names[q] for q in range(len(names)) if (int(m) >> q) & 1]]
+
+    ref = S.SearcherRef(N, 1.0, targets, cues, score_fn, np.random.RandomState(seed), search_nframes=K,
+                        image_grid_shape=(g, g), search_budget=budget, confidence_threshold=thr)
+    holder["ref"] = ref
+    ts_ref = ref.search()
+    assert next(calls, None) is None, "the HIP pipeline scored a batch the reference loop never asks for"
+    return ref, ts_ref
+
+
+def test_l2_teacher_forced_bench_workload():
+    """BASELINE configs[1] at its own shape -- the workload bench.py times: N = 3600, grid 16x16 (one 1520x3200 grid
+    image per iteration), K = 8, threshold 0.6, budget 1000, sampler seed 2025, max_batch = 256 (verification batches of
+    ~180 frames: one chunk) -- teacher-forced: (a) the recorded confidences replayed through the oracle searcher give
+    the same sampled seconds, histories and keyframes, bit for bit; (b) the first grid image is byte-identical to the
+    oracle's ingest and its detector scores, and those of verification frames, are within 1e-3 of the CPU oracle;
+    (c) the 256-cell aggregation replays bit-exactly through the reference loop."""
+    from oracle import searcher_ref as S, resize_ref as R, owl_ref
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_frames_numpy, synthetic_video
+    from tstar_amd import weights as W
+    N, g, K, seed = 3600, 16, 8, 2025
+    h = OWLInterface(synthetic_seed=0, max_batch=256)
+    rec = _Recorder(h)
+    s = TStarSearcher(synthetic_video(N, seed=0), h, ["couch"], ["tv", "chair"], search_nframes=K, image_grid_shape=(g, g),
+                      search_budget=1000, confidence_threshold=0.6, rng=np.random.RandomState(seed), keep_visual_history=False)
+    log = []
+    orig = s.sample_frames
+    s.sample_frames = lambda num: (lambda r: (log.append(list(r[0])), r)[1])(orig(num))
+    frames, ts = s.search()
+    assert s.iterations == 4 and len(ts) == K                     # 1000 -> 744 -> 488 -> 232 -> -24
+    ref, ts_ref = _replay_through_oracle(rec, h, ["couch"], ["tv", "chair"], N, g, K, 1000, 0.6, seed)
+    assert [it["secs"] for it in ref.trace] == log
+    assert ts_ref == [float(t) for t in ts]
+    for i in range(s.iterations):
+        assert np.array_equal(np.asarray(s.Score_history[i]), ref.Score_history[i])
+        assert np.array_equal(np.asarray(s.non_visiting_history[i]), ref.unvisited_history[i])
+        assert np.array_equal(np.asarray(s.P_history[i]), ref.P_history[i])          # host numpy on both sides: exact
+    assert np.array_equal(s.score_distribution, ref.score)
+    assert s.frames_scored == 4 * 256 + sum(len(it["verify"]) for it in ref.trace)
+    # (b) ingest + detector at 1520x3200 against the CPU oracle
+    first = rec.calls[0]
+    grid_ref = R.frames_to_grid(list(synthetic_frames_numpy(log[0], N, seed=0)), g, g)
+    assert first["images"][0].shape == (1520, 3200, 3) and np.array_equal(first["images"][0], grid_ref)
+    sd = W.synthetic_state_dict(0)
+    wv = W.unpack_blob(W.pack_blob(sd, W.vision_spec()), W.vision_spec())
+    qe = h.scorer.get_query_embeds()
+    qm = np.ones(len(h.texts), bool)
+    o = owl_ref.detect(R.owl_preprocess(grid_ref)[None], qe, wv, 1520, 3200, query_mask=qm)
+    err_grid = float(np.abs(o["dense"][0][0] - first["scores"][0]).max())
+    assert err_grid < 1e-3
+    ver = rec.calls[1]
+    assert ver["images"].shape[0] > 100                             # ~180 candidate frames in one lock-step batch
+    err_ver = 0.0
+    for j in (0, ver["images"].shape[0] // 2, ver["images"].shape[0] - 1):
+        o2 = owl_ref.detect(R.owl_preprocess(ver["images"][j])[None], qe, wv, 285, 600, query_mask=qm)
+        err_ver = max(err_ver, float(np.abs(o2["dense"][0][0] - ver["scores"][j]).max()))
+    assert err_ver < 1e-3
+    # (c) the 16x16 cell aggregation of every grid call replays bit-exactly through the reference loop
+    texts = [list(t) for t in h.texts]
+    o2w = {"couch": 1.0, "tv": 0.5, "chair": 0.5}
+    for c in [c for c in rec.calls if c["rows"] == g]:
+        keep = c["scores"][0] > np.float32(0.005)
+        cm, nm = S.image_grid_score(c["boxes"][0][keep], c["labels"][0][keep], c["scores"][0][keep], texts, o2w, 1520, 3200, g, g)
+        assert np.array_equal(c["conf"][0].reshape(g, g), cm)
+        for cell in range(g * g):
+            want = 0
+            for nme in nm[cell]:
+                want |= 1 << [t[0] for t in texts].index(nme)
+            assert int(c["mask"][0][cell]) == want
+    print(f"configs[1] teacher-forced: keyframes {ts_ref}, {sum(len(it['verify']) for it in ref.trace)} verification calls, "
+          f"max |score - oracle| grid {err_grid:.2e} / verify {err_ver:.2e}")
 
 
 def test_generic_heuristic_path_matches_fast_path():
@@ -288,7 +390,7 @@ def test_g1_reference_trajectories_on_device(golden_dir, case):
                       rng=np.random.RandomState(np_seed), keep_visual_history=False)
     log = []
     orig = s.sample_frames
-    s.sample_frames = lambda num: (lambda r: (log.append(list(r)), r)[1])(orig(num))
+    s.sample_frames = lambda num: (lambda r: (log.append(list(r[0])), r)[1])(orig(num))     # as make_goldens.py wraps it
     frames, ts = s.search()
     assert log == g["secs"].tolist()
     assert [float(t) for t in ts] == g["time_stamps"].tolist()
@@ -318,7 +420,7 @@ def test_g9_end_to_end_vs_reference(golden_dir):
                       rng=np.random.RandomState(np_seed), keep_visual_history=False)
     log = []
     orig = s.sample_frames
-    s.sample_frames = lambda num: (lambda r: (log.append(list(r)), r)[1])(orig(num))
+    s.sample_frames = lambda num: (lambda r: (log.append(list(r[0])), r)[1])(orig(num))     # as make_goldens.py wraps it
     frames, ts = s.search()
     ref_secs = g["secs"].tolist()
     assert log[0] == ref_secs[0]
@@ -447,9 +549,10 @@ def test_query_sets_are_independent():
 
 
 def test_reference_style_manual_loop_equals_search():
-    """Drive the searcher the way the reference's own ``search()`` body does (:444-491) -- sample_frames, one grid
-    detector pass, the PUBLIC ``update_frame_distribution`` with host confidence maps, then ``verify_and_remove_target``
-    frame by frame -- and compare with ``search()`` (device confidences, speculative batched verification) on an
+    """Drive the searcher through its PUBLIC methods in the order and with the keywords the reference's own
+    ``search()`` body uses (:444-491): ``sample_frames`` -> ``create_image_grid`` -> ``score_image_grids`` (host image,
+    ``inference_detector``, Python cell loop) -> ``update_frame_distribution`` -> ``verify_and_remove_target`` frame by
+    frame -- and compare with ``search()`` (device grid, device confidences, speculative batched verification) on an
     identically seeded searcher: same sampled seconds, same histories, same keyframes."""
     from tstar_amd.interface_heuristic import OWLInterface
     from tstar_amd.interface_searcher import TStarSearcher
@@ -466,19 +569,21 @@ def test_reference_style_manual_loop_equals_search():
     frames_a, ts_a = a.search()
 
     b = make()
-    rows, cols = b.image_grid_shape
     while b.remaining_targets and b.search_budget > 0:
-        secs = b.sample_frames(rows * cols)
-        b.search_budget -= rows * cols
-        grid = b._device_grid(secs)
-        res = h.score_batch(grid.unsqueeze(0), rows, cols)
-        conf_maps = res.cell_conf.cpu().numpy().reshape(1, rows, cols)
-        masks = res.cell_mask[0].cpu().numpy().astype(np.uint32)
-        det_maps = [[b._names_from_mask(int(m)) for m in masks]]
-        confs, objs = b.update_frame_distribution(secs, conf_maps, det_maps)
-        assert len(confs) == len(secs) and objs == det_maps[0][:len(secs)]
+        rows, cols = b.image_grid_shape
+        n = rows * cols
+        secs, frames = b.sample_frames(n)                                  # (seconds, 800x380 frames), as the reference
+        assert len(frames) == n and frames[0].shape == (380, 800, 3) and frames[0].dtype == np.uint8
+        b.search_budget -= n
+        grid_image = b.create_image_grid(frames, rows, cols)
+        assert grid_image.shape == (95 * rows, 200 * cols, 3)
+        assert np.array_equal(grid_image, b.create_image_grid(list(frames), rows, cols))   # host frames -> same bytes
+        conf_maps, det_maps = b.score_image_grids(images=[grid_image], image_grids=b.image_grid_shape)
+        confs, objs = b.update_frame_distribution(sampled_frame_indices=secs, confidence_maps=conf_maps,
+                                                  detected_objects_maps=det_maps)
+        assert len(confs) == len(secs)
         for sec, names in zip(secs, objs):
-            b.verify_and_remove_target(sec, names, b.confidence_threshold)
+            b.verify_and_remove_target(frame_sec=sec, detected_objects=names, confidence_threshold=b.confidence_threshold)
     frames_b, ts_b = b.pop_frames(b.video_path, b.search_nframes)
     assert list(ts_a) == list(ts_b)
     assert np.array_equal(frames_a, frames_b)

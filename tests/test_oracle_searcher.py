@@ -106,3 +106,15 @@ def test_restatements_equal_numpy():
         assert S.percentile75(a) == np.percentile(a, 75)
     with pytest.raises(ValueError, match="Fewer non-zero"):
         S.legacy_choice(np.random.RandomState(0), 4, 3, np.array([1.0, 0, 0, 0]))
+
+
+def test_g11_topk_selection_matches_reference(golden_dir):
+    """oracle.topk_seconds vs the picks of the reference's extract_frames (val_qa_results.py:90-110, imported
+    unmodified by make_goldens.g11_topk): equal where no tie is cut, equal values (and lowest-index ties) where one is."""
+    n_cut = 0
+    for name, dist, k, clip, ref in GU.g11_cases(golden_dir):
+        dc, start = S.topk_normalised_clip(dist, clip)
+        got = S.topk_seconds(dist, k, clip)
+        assert len(got) == min(k, len(dc)), name
+        n_cut += GU.check_topk_against_reference(got, ref, dc, start)
+    assert n_cut >= 3          # the flat / all-zero / plateau cases do cut through ties

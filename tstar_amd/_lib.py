@@ -41,7 +41,10 @@ SIGNATURES = {
     "tstar_searcher_apply_grid": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "tstar_searcher_set_spline": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "tstar_searcher_sampler_prep": (_i, [_vp, _i, C.c_double, _vp, _vp]),
-    "tstar_searcher_pop_prep": (_i, [_vp, _vp]),
+    "tstar_searcher_pop_prep": (_i, [_vp, _vp, _vp, _vp]),
+    "tstar_searcher_window_spread": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "tstar_searcher_visited": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "tstar_searcher_write": (_i, [_vp, _i, _vp, _vp]),
     "tstar_searcher_draw": (_i, [_vp, _vp, _i, _vp, _vp]),
     "tstar_searcher_exclude": (_i, [_vp, _vp, _i, _vp]),
     "tstar_searcher_set_scores": (_i, [_vp, _vp, _vp, _i, _vp]),

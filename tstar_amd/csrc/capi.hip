@@ -7,6 +7,8 @@
 #include "owl_weights.h"
 #include <math.h>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string.h>
 #include <unordered_map>
 #include <vector>
@@ -14,6 +16,20 @@
 namespace tstar {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+
+int ensure_dyn_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("ensure_dyn_lds: hipGetDevice failed"); return 2; }
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(kernel, dev);
+    if (done.count(key)) return 0;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)); return 2; }
+    done.insert(key);
+    return 0;
+}
 
 // ---------------------------------------------------------------- small text-tower kernels
 // x[q*T + t, :] = tok_emb[ids[q,t], :] + pos_emb[t, :]   (OwlViTTextEmbeddings, modeling_owlvit.py:356-372)
@@ -76,7 +92,8 @@ struct tstar_owl {
     // query sets: TSTAR_OWL_MAX_SETS independent (question) slots, each up to 32 queries; every image of
     // a score call names the slot it is scored against (several (video, question) items batched together)
     int Q[TSTAR_OWL_MAX_SETS] = {0};
-    float *q_raw = nullptr, *qn = nullptr, *qweight = nullptr;       // [sets][32][512] / [sets][32]
+    float *q_raw = nullptr, *qn = nullptr;                           // [sets][32][512]
+    double* qweight = nullptr;                                       // [sets][32] object2weight per query (float64, as the reference's Python floats)
     uint8_t* qmask = nullptr;                                        // [sets][32]
     int *d_setQ = nullptr, *d_image_set = nullptr;
     int image_set_cap = 0;
@@ -198,7 +215,7 @@ static int preprocess_chunk(tstar_owl* h, const uint8_t* d_images, int B, int H,
 extern "C" {
 
 const char* tstar_last_error(void) { return g_err.c_str(); }
-int tstar_abi_version(void) { return 1; }
+int tstar_abi_version(void) { return 2; }
 size_t tstar_owl_vision_blob_floats(void) { return vision_floats(); }
 size_t tstar_owl_text_blob_floats(void) { return text_floats(); }
 
@@ -263,7 +280,8 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
     alloc(&h->d_lut, 768);
     constexpr int NSQ = TSTAR_OWL_MAX_SETS * TSTAR_OWL_MAX_QUERIES;
     alloc(&h->q_raw, (size_t)NSQ * PROJ); alloc(&h->qn, (size_t)NSQ * PROJ);
-    alloc(&h->qweight, NSQ);
+    if (e == hipSuccess) e = hipMalloc(&h->qweight, NSQ * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(h->qweight, 0, NSQ * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->qmask, NSQ);
     if (e == hipSuccess) e = hipMemset(h->qmask, 0, NSQ);
     if (e == hipSuccess) e = hipMalloc(&h->d_setQ, TSTAR_OWL_MAX_SETS * sizeof(int));
@@ -299,19 +317,19 @@ int tstar_owl_destroy(tstar_owl* h) {
 
 #define CHECK_SET(set, fn) TSTAR_REQUIRE((set) >= 0 && (set) < TSTAR_OWL_MAX_SETS, fn ": query_set must be in 0..31")
 
-static int finish_queries(tstar_owl* h, int set, const uint8_t* h_mask, const float* h_w, int Q, hipStream_t s) {
+static int finish_queries(tstar_owl* h, int set, const uint8_t* h_mask, const double* h_w, int Q, hipStream_t s) {
     const size_t qo = (size_t)set * TSTAR_OWL_MAX_QUERIES;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->q_raw + qo * PROJ, h->qn + qo * PROJ, 1e-6f);
     TSTAR_HIP_CHECK(hipGetLastError());
     TSTAR_HIP_CHECK(hipMemcpyAsync(h->qmask + qo, h_mask, Q, hipMemcpyHostToDevice, s));
-    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight + qo, h_w, Q * sizeof(float), hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight + qo, h_w, Q * sizeof(double), hipMemcpyHostToDevice, s));
     h->Q[set] = Q;
     TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_setQ, h->Q, sizeof(h->Q), hipMemcpyHostToDevice, s));
     TSTAR_HIP_CHECK(hipStreamSynchronize(s));
     return TSTAR_OK;
 }
 
-int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_ids, const int32_t* h_am, const float* h_w, int Q,
+int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_ids, const int32_t* h_am, const double* h_w, int Q,
                           void* stream) {
     TSTAR_REQUIRE(h && h_ids && h_am && h_w, "tstar_owl_set_queries: null argument");
     CHECK_SET(query_set, "tstar_owl_set_queries");
@@ -349,7 +367,7 @@ int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_ids, con
     return finish_queries(h, query_set, qm.data(), h_w, Q, s);
 }
 
-int tstar_owl_set_query_embeds(tstar_owl* h, int query_set, const float* h_qe, const uint8_t* h_mask, const float* h_w,
+int tstar_owl_set_query_embeds(tstar_owl* h, int query_set, const float* h_qe, const uint8_t* h_mask, const double* h_w,
                                int Q, void* stream) {
     TSTAR_REQUIRE(h && h_qe && h_mask && h_w, "tstar_owl_set_query_embeds: null argument");
     CHECK_SET(query_set, "tstar_owl_set_query_embeds");
@@ -360,12 +378,12 @@ int tstar_owl_set_query_embeds(tstar_owl* h, int query_set, const float* h_qe, c
     return finish_queries(h, query_set, h_mask, h_w, Q, s);
 }
 
-int tstar_owl_set_class_weights(tstar_owl* h, int query_set, const float* h_w, int Q, void* stream) {
+int tstar_owl_set_class_weights(tstar_owl* h, int query_set, const double* h_w, int Q, void* stream) {
     TSTAR_REQUIRE(h && h_w, "tstar_owl_set_class_weights: null argument");
     CHECK_SET(query_set, "tstar_owl_set_class_weights");
     TSTAR_REQUIRE(Q == h->Q[query_set] && Q >= 1, "tstar_owl_set_class_weights: Q does not match the installed queries");
     hipStream_t s = (hipStream_t)stream;
-    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight + (size_t)query_set * TSTAR_OWL_MAX_QUERIES, h_w, Q * sizeof(float),
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight + (size_t)query_set * TSTAR_OWL_MAX_QUERIES, h_w, Q * sizeof(double),
                                    hipMemcpyHostToDevice, s));
     TSTAR_HIP_CHECK(hipStreamSynchronize(s));
     return TSTAR_OK;

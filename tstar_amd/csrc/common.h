@@ -27,6 +27,11 @@ void set_error(const std::string& msg);
         }                                                                            \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for kernels that need more than 64 KB of dynamic LDS: set once per
+// (kernel, device) under a mutex -- launches may come from several host threads and a process may use more than
+// one device (the attribute is applied to the kernel's code object of the CURRENT device).  Returns TSTAR_OK / TSTAR_ERR_HIP.
+int ensure_dyn_lds(const void* kernel, int bytes);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

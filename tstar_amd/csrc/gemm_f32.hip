@@ -425,12 +425,7 @@ template <class CF, int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     constexpr int lds = lds_bytes<WMODE>(CF::BM, CF::BN);
     auto kern = gemm_f32_kernel<CF, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     const int nwg = cdiv(g.M, CF::BM) * (g.N / CF::BN);
     const bool prof = prof_enabled();
     if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K);
@@ -444,12 +439,7 @@ template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
     constexpr int lds = lds_bytes<WMODE>(128, 128);
     auto kern = gemm_f32_hybrid_kernel<WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     const int nt = g.N / 128;
     const int nwg = (g.m_split / 128) * nt + cdiv(g.M - g.m_split, 64) * nt;
     const bool prof = prof_enabled();

@@ -26,7 +26,7 @@ struct DetectRowsArgs {
 };
 int detect_rows(const DetectRowsArgs& a, hipStream_t s);
 
-int cell_reduce(const float* scores, const int* labels, const float* xyxy, const float* qweight, const int* image_set, int B, int np,
+int cell_reduce(const float* scores, const int* labels, const float* xyxy, const double* qweight, const int* image_set, int B, int np,
                 int img_w, int img_h, int grows, int gcols, float thr, double* cell_conf, uint32_t* cell_mask,
                 int* n_kept, hipStream_t s);
 

@@ -127,20 +127,23 @@ int detect_rows(const DetectRowsArgs& a, hipStream_t s) {
     return TSTAR_OK;
 }
 
-// One block per image.  conf is >= 0, so max over f32 == max over its bit pattern.
+// One block per image.  conf = float64(score) * float64(weight): the reference multiplies an np.float32 scalar by a
+// Python float (interface_searcher.py:136-137), which is a float64 product under its pinned numpy 1.26 (exact, and
+// equal to the float32 product, for the default weights 1.0 / 0.5; a user weight such as 0.7 needs the f64 form).
+// conf is >= 0, so max over f64 == max over its bit pattern.
 __global__ __launch_bounds__(256) void cell_reduce_kernel(const float* __restrict__ scores, const int* __restrict__ labels,
-                                                          const float* __restrict__ xyxy, const float* __restrict__ qweight_all,
+                                                          const float* __restrict__ xyxy, const double* __restrict__ qweight_all,
                                                           const int* __restrict__ image_set, int np, int img_w, int img_h, int grows, int gcols, float thr,
                                                           double* __restrict__ cell_conf, uint32_t* __restrict__ cell_mask,
                                                           int* __restrict__ n_kept) {
-    extern __shared__ uint32_t sm[];
+    extern __shared__ unsigned long long sm[];
     const int ncell = grows * gcols;
-    uint32_t* cbits = sm;
-    uint32_t* cmask = sm + ncell;
+    unsigned long long* cbits = sm;
+    uint32_t* cmask = reinterpret_cast<uint32_t*>(sm + ncell);
     __shared__ int kept;
     const int b = blockIdx.x;
-    const float* qweight = qweight_all + (image_set ? image_set[b] : 0) * 32;
-    for (int i = threadIdx.x; i < ncell; i += blockDim.x) { cbits[i] = 0u; cmask[i] = 0u; }
+    const double* qweight = qweight_all + (image_set ? image_set[b] : 0) * 32;
+    for (int i = threadIdx.x; i < ncell; i += blockDim.x) { cbits[i] = 0ull; cmask[i] = 0u; }
     if (threadIdx.x == 0) kept = 0;
     __syncthreads();
     // cell sizes are Python floats in the reference (interface_searcher.py:117-118)
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void cell_reduce_kernel(const float* __restric
         const float s = scores[r];
         if (s > thr) {
             const int lab = labels[r];
-            const float conf = s * qweight[lab];
+            const double conf = (double)s * qweight[lab];
             const f32x4 bb = *reinterpret_cast<const f32x4*>(xyxy + r * 4);
             const float cx = (bb[0] + bb[2]) * 0.5f;          // f32 add, exact halving
             const float cy = (bb[1] + bb[3]) * 0.5f;
@@ -159,24 +162,24 @@ __global__ __launch_bounds__(256) void cell_reduce_kernel(const float* __restric
             gy = gy < grows - 1 ? gy : grows - 1;
             gx = gx < 0 ? 0 : gx; gy = gy < 0 ? 0 : gy;
             const int cell = gy * gcols + gx;
-            atomicMax(&cbits[cell], __float_as_uint(conf));
+            atomicMax(&cbits[cell], (unsigned long long)__double_as_longlong(conf));
             atomicOr(&cmask[cell], 1u << lab);
             atomicAdd(&kept, 1);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ncell; i += blockDim.x) {
-        cell_conf[(size_t)b * ncell + i] = (double)__uint_as_float(cbits[i]);
+        cell_conf[(size_t)b * ncell + i] = __longlong_as_double((long long)cbits[i]);
         cell_mask[(size_t)b * ncell + i] = cmask[i];
     }
     if (threadIdx.x == 0 && n_kept) n_kept[b] = kept;
 }
 
-int cell_reduce(const float* scores, const int* labels, const float* xyxy, const float* qweight, const int* image_set,
+int cell_reduce(const float* scores, const int* labels, const float* xyxy, const double* qweight, const int* image_set,
                 int B, int np, int img_w, int img_h, int grows, int gcols, float thr, double* cell_conf, uint32_t* cell_mask,
                 int* n_kept, hipStream_t s) {
     TSTAR_REQUIRE(grows > 0 && gcols > 0 && grows * gcols <= 4096, "cell_reduce: grid must have 1..4096 cells");
-    const size_t lds = (size_t)grows * gcols * 2 * sizeof(uint32_t);
+    const size_t lds = (size_t)grows * gcols * (sizeof(unsigned long long) + sizeof(uint32_t));
     hipLaunchKernelGGL(cell_reduce_kernel, dim3(B), dim3(256), lds, s, scores, labels, xyxy, qweight, image_set, np, img_w, img_h,
                        grows, gcols, thr, cell_conf, cell_mask, n_kept);
     TSTAR_HIP_CHECK(hipGetLastError());

@@ -92,12 +92,14 @@ __device__ __forceinline__ double lerp75(double a, double b, double g) {
 __global__ __launch_bounds__(ST) void apply_grid_kernel(double* __restrict__ score, double* __restrict__ unvisited,
                                                         const int* __restrict__ secs, const double* __restrict__ conf,
                                                         int n, int N, int window, int* __restrict__ vis_x,
-                                                        double* __restrict__ vis_y, int* __restrict__ n_vis, int use_lds) {
+                                                        double* __restrict__ vis_y, int* __restrict__ n_vis, int use_lds,
+                                                        int do_write, int do_compact) {
     __shared__ double s_lohi[2];
     __shared__ int s_cnt[ST / 64];
     extern __shared__ double s_dyn[];            // use_lds: [score N][conf n][secs n (int)]
     const int t = threadIdx.x;
-    for (int i = t; i < n; i += ST) { unvisited[secs[i]] = 0.0; score[secs[i]] = conf[i]; }
+    if (do_write)
+        for (int i = t; i < n; i += ST) { unvisited[secs[i]] = 0.0; score[secs[i]] = conf[i]; }
     // order statistics of conf by rank counting (n <= a few hundred)
     const double vi = n * 0.75 + (1 + 0.75 * (1 - 1 - 1)) - 1;
     int lo = (int)floor(vi);
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(ST) void apply_grid_kernel(double* __restrict__ sco
         __threadfence_block();
         __syncthreads();
     }
+    if (!do_compact) return;
     // ordered compaction of the visited frames
     const int per = (N + ST - 1) / ST;
     const int b0 = t * per, b1 = (b0 + per < N) ? b0 + per : N;
@@ -326,12 +329,20 @@ __global__ __launch_bounds__(ST) void sampler_prep_kernel(const double* __restri
 }
 
 // pop_frames' weights (interface_searcher.py:369): p = score / score.sum()
+// Also reports what numpy's choice() checks before drawing (mtrand.pyx, legacy RandomState.choice):
+// info_nnz = count_nonzero(p > 0), info_sum = score.sum() (0 or NaN -> p holds NaN -> "probabilities contain NaN").
 __global__ __launch_bounds__(ST) void pop_prep_kernel(const double* __restrict__ score, double* __restrict__ p,
-                                                      double* __restrict__ cdf, int N, SumProgram sp) {
+                                                      double* __restrict__ cdf, int N, SumProgram sp,
+                                                      int* __restrict__ info_nnz, double* __restrict__ info_sum) {
     extern __shared__ double scratch[];
+    __shared__ int s_nnz;
+    if (threadIdx.x == 0) s_nnz = 0;
     const double s = block_np_sum(score, sp, scratch);
-    for (int i = threadIdx.x; i < N; i += ST) p[i] = score[i] / s;
+    int nnz = 0;
+    for (int i = threadIdx.x; i < N; i += ST) { const double v = score[i] / s; p[i] = v; nnz += v > 0.0; }
+    atomicAdd(&s_nnz, nnz);
     block_cdf(p, cdf, N);
+    if (threadIdx.x == 0) { *info_nnz = s_nnz; *info_sum = s; }
 }
 
 // choice()'s retry step: p[found] = 0; cdf = cumsum(p); cdf /= cdf[-1]
@@ -365,6 +376,7 @@ struct tstar_searcher {
     double *score = nullptr, *unvisited = nullptr, *P = nullptr, *p = nullptr, *cdf = nullptr;
     double *d_t = nullptr, *d_c = nullptr, *d_vis_y = nullptr, *d_x = nullptr, *d_vals = nullptr;
     int *d_secs = nullptr, *d_vis_x = nullptr, *d_flag = nullptr, *d_idx = nullptr;
+    double* d_info = nullptr;
     int cap = 0;                 // capacity of the small staging arrays
     SumProgram sp;
     size_t lds = 0;
@@ -377,7 +389,7 @@ extern "C" {
 int tstar_searcher_destroy(tstar_searcher* s) {
     if (!s) return TSTAR_OK;
     void* ptrs[] = {s->score, s->unvisited, s->P, s->p, s->cdf, s->d_t, s->d_c, s->d_vis_y, s->d_x, s->d_vals,
-                    s->d_secs, s->d_vis_x, s->d_flag, s->d_idx, s->sp.d_leaf_off, s->sp.d_leaf_len, s->sp.d_ops};
+                    s->d_secs, s->d_vis_x, s->d_flag, s->d_idx, s->d_info, s->sp.d_leaf_off, s->sp.d_leaf_len, s->sp.d_ops};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete s;
     return TSTAR_OK;
@@ -401,6 +413,7 @@ int tstar_searcher_create(tstar_searcher** out, int n_frames, double init_score,
     ad(&s->score, N); ad(&s->unvisited, N); ad(&s->P, N); ad(&s->p, N); ad(&s->cdf, N);
     ad(&s->d_t, s->cap + 8); ad(&s->d_c, s->cap + 8); ad(&s->d_vis_y, s->cap); ad(&s->d_x, s->cap); ad(&s->d_vals, s->cap);
     ai(&s->d_secs, s->cap); ai(&s->d_vis_x, s->cap); ai(&s->d_flag, 4); ai(&s->d_idx, s->cap);
+    ad(&s->d_info, 2);
     std::vector<int> lo, ll; std::vector<signed char> ops;
     build_program(0, N, lo, ll, ops);
     s->sp.n_leaf = (int)lo.size(); s->sp.n_ops = (int)ops.size();
@@ -428,6 +441,18 @@ int tstar_searcher_create(tstar_searcher** out, int n_frames, double init_score,
     return TSTAR_OK;
 }
 
+static int launch_apply(tstar_searcher* s, const double* d_conf, int n, int window, int do_write, int do_compact, hipStream_t st) {
+    // LDS working set of the window spread: score (N f64) + conf (n f64) + secs (n i32); global fallback beyond 144 KB
+    const size_t need = (size_t)s->N * 8 + (size_t)n * 12;
+    const int use_lds = need <= 144 * 1024;
+    const size_t dyn = use_lds ? need : 0;
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(apply_grid_kernel), 144 * 1024)) return rc;
+    hipLaunchKernelGGL(apply_grid_kernel, dim3(1), dim3(ST), dyn, st, s->score, s->unvisited, s->d_secs, d_conf, n, s->N, window,
+                       s->d_vis_x, s->d_vis_y, s->d_flag, use_lds, do_write, do_compact);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
 int tstar_searcher_apply_grid(tstar_searcher* s, const int32_t* h_secs, const double* d_conf, int n,
                               int* h_n_visited, int32_t* h_vis_x, double* h_vis_y, void* stream) {
     TSTAR_REQUIRE(s && h_secs && d_conf && h_n_visited && h_vis_x && h_vis_y, "tstar_searcher_apply_grid: null argument");
@@ -435,25 +460,42 @@ int tstar_searcher_apply_grid(tstar_searcher* s, const int32_t* h_secs, const do
     for (int i = 0; i < n; ++i) TSTAR_REQUIRE(h_secs[i] >= 0 && h_secs[i] < s->N, "tstar_searcher_apply_grid: second out of range");
     hipStream_t st = (hipStream_t)stream;
     TSTAR_HIP_CHECK(hipMemcpyAsync(s->d_secs, h_secs, n * sizeof(int), hipMemcpyHostToDevice, st));
-    // LDS working set of the window spread: score (N f64) + conf (n f64) + secs (n i32); global fallback beyond 144 KB
-    const size_t need = (size_t)s->N * 8 + (size_t)n * 12;
-    const int use_lds = need <= 144 * 1024;
-    const size_t dyn = use_lds ? need : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TSTAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(apply_grid_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(apply_grid_kernel, dim3(1), dim3(ST), dyn, st, s->score, s->unvisited, s->d_secs, d_conf, n, s->N, 5,
-                       s->d_vis_x, s->d_vis_y, s->d_flag, use_lds);
-    TSTAR_HIP_CHECK(hipGetLastError());
+    RC(launch_apply(s, d_conf, n, 5, 1, 1, st));
     TSTAR_HIP_CHECK(hipMemcpyAsync(h_n_visited, s->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     TSTAR_HIP_CHECK(hipStreamSynchronize(st));
     const int nv = *h_n_visited;
     TSTAR_HIP_CHECK(hipMemcpyAsync(h_vis_x, s->d_vis_x, nv * sizeof(int), hipMemcpyDeviceToHost, st));
     TSTAR_HIP_CHECK(hipMemcpyAsync(h_vis_y, s->d_vis_y, nv * sizeof(double), hipMemcpyDeviceToHost, st));
     TSTAR_HIP_CHECK(hipStreamSynchronize(st));
+    return TSTAR_OK;
+}
+
+int tstar_searcher_window_spread(tstar_searcher* s, const int32_t* h_secs, const double* h_conf, int n, int window,
+                                 void* stream) {
+    TSTAR_REQUIRE(s && h_secs && h_conf, "tstar_searcher_window_spread: null argument");
+    TSTAR_REQUIRE(n >= 1 && n <= s->cap && window >= 0 && window <= 4096, "tstar_searcher_window_spread: bad n or window");
+    for (int i = 0; i < n; ++i) TSTAR_REQUIRE(h_secs[i] >= 0 && h_secs[i] < s->N, "tstar_searcher_window_spread: second out of range");
+    hipStream_t st = (hipStream_t)stream;
+    TSTAR_HIP_CHECK(hipMemcpyAsync(s->d_secs, h_secs, n * sizeof(int), hipMemcpyHostToDevice, st));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(s->d_vals, h_conf, n * sizeof(double), hipMemcpyHostToDevice, st));
+    RC(launch_apply(s, s->d_vals, n, window, 0, 0, st));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(st));     // host staging buffers are reused by the next call
+    return TSTAR_OK;
+}
+
+int tstar_searcher_visited(tstar_searcher* s, int* h_n_visited, int32_t* h_vis_x, double* h_vis_y, void* stream) {
+    TSTAR_REQUIRE(s && h_n_visited && h_vis_x && h_vis_y, "tstar_searcher_visited: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    // n = 0 samples: no write-back, no spread (the percentile of an empty set is never used), compaction only
+    RC(launch_apply(s, s->d_vals, 0, 0, 0, 1, st));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h_n_visited, s->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(st));
+    const int nv = *h_n_visited;
+    if (nv > 0) {
+        TSTAR_HIP_CHECK(hipMemcpyAsync(h_vis_x, s->d_vis_x, nv * sizeof(int), hipMemcpyDeviceToHost, st));
+        TSTAR_HIP_CHECK(hipMemcpyAsync(h_vis_y, s->d_vis_y, nv * sizeof(double), hipMemcpyDeviceToHost, st));
+        TSTAR_HIP_CHECK(hipStreamSynchronize(st));
+    }
     return TSTAR_OK;
 }
 
@@ -480,11 +522,14 @@ int tstar_searcher_sampler_prep(tstar_searcher* s, int num, double add, int* h_f
     return TSTAR_OK;
 }
 
-int tstar_searcher_pop_prep(tstar_searcher* s, void* stream) {
-    TSTAR_REQUIRE(s, "tstar_searcher_pop_prep: null argument");
+int tstar_searcher_pop_prep(tstar_searcher* s, int* h_nnz, double* h_sum, void* stream) {
+    TSTAR_REQUIRE(s && h_nnz && h_sum, "tstar_searcher_pop_prep: null argument");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pop_prep_kernel, dim3(1), dim3(ST), s->lds, st, s->score, s->p, s->cdf, s->N, s->sp);
+    hipLaunchKernelGGL(pop_prep_kernel, dim3(1), dim3(ST), s->lds, st, s->score, s->p, s->cdf, s->N, s->sp, s->d_flag + 2, s->d_info);
     TSTAR_HIP_CHECK(hipGetLastError());
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h_nnz, s->d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h_sum, s->d_info, sizeof(double), hipMemcpyDeviceToHost, st));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(st));
     return TSTAR_OK;
 }
 
@@ -532,6 +577,16 @@ int tstar_searcher_read_state(tstar_searcher* s, double* h_out, void* stream) {
     TSTAR_HIP_CHECK(hipMemcpyAsync(h_out + s->N, s->score, nb, hipMemcpyDeviceToHost, st));
     TSTAR_HIP_CHECK(hipMemcpyAsync(h_out + 2 * (size_t)s->N, s->unvisited, nb, hipMemcpyDeviceToHost, st));
     TSTAR_HIP_CHECK(hipStreamSynchronize(st));
+    return TSTAR_OK;
+}
+
+int tstar_searcher_write(tstar_searcher* s, int which, const double* h_in, void* stream) {
+    TSTAR_REQUIRE(s && h_in, "tstar_searcher_write: null argument");
+    TSTAR_REQUIRE(which >= 0 && which <= 2, "tstar_searcher_write: which must be 0 (score), 1 (non_visiting) or 2 (P)");
+    double* dst[] = {s->score, s->unvisited, s->P};
+    hipStream_t st = (hipStream_t)stream;
+    TSTAR_HIP_CHECK(hipMemcpyAsync(dst[which], h_in, s->N * sizeof(double), hipMemcpyHostToDevice, st));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(st));     // the host buffer may be reused by the caller
     return TSTAR_OK;
 }
 

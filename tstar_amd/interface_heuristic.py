@@ -55,7 +55,7 @@ class HeuristicInterface:
 class OWLInterface(HeuristicInterface):
     def __init__(self, model_name_or_path: str = "google/owlvit-base-patch32", device: str = "cuda",
                  max_batch: int = 32, synthetic_seed: Optional[int] = None, state_dict: Optional[Dict] = None,
-                 weights_dtype: str = "f32"):
+                 weights_dtype: str = "f32", allow_standin_tokenizer: Optional[bool] = None):
         """``device`` must be a HIP device (default "cuda" as in the reference, :201).
 
         Weights: ``state_dict`` (HF names) if given; else a local safetensors checkpoint of
@@ -64,7 +64,12 @@ class OWLInterface(HeuristicInterface):
         ``weights_dtype="bf16"`` rounds every weight matrix to bfloat16 (BASELINE config 5) and runs the
         GEMMs on the bf16 matrix pipe with the float32 activations split exactly into three bf16 terms:
         products are exact and accumulate in float32, so the result equals a CPU float32 run on the
-        same rounded weights up to summation order."""
+        same rounded weights up to summation order.
+
+        ``allow_standin_tokenizer``: the hash stand-in of tstar_amd.tokenizer is only meaningful with
+        synthetic weights; default (None) = allowed exactly when the weights are the seeded synthetic
+        ones.  With a real checkpoint and no CLIP vocab on disk, installing queries raises instead of
+        feeding made-up ids to the real text tower."""
         import torch
         from .owl import OwlScorer
         if not str(device).startswith("cuda"):
@@ -86,6 +91,9 @@ class OWLInterface(HeuristicInterface):
                     "for seeded synthetic OWL-ViT-B/32 weights or state_dict=<HF state dict>")
         else:
             self.weights_source = "state_dict"
+        if allow_standin_tokenizer is None:
+            allow_standin_tokenizer = self.weights_source.startswith("synthetic(")
+        self.allow_standin_tokenizer = bool(allow_standin_tokenizer)
         if weights_dtype not in ("f32", "bf16", "f32_split"):
             raise ValueError("weights_dtype must be 'f32', 'bf16' or 'f32_split'")
         if weights_dtype == "bf16":
@@ -104,13 +112,13 @@ class OWLInterface(HeuristicInterface):
     def reparameterize_object_list(self, target_objects: List[str], cue_objects: List[str]):
         combined = list(target_objects) + list(cue_objects)
         self.texts = [[obj.strip()] for obj in combined] + [[' ']]
-        ids, am = encode_queries(self.texts, self.model_name_or_path)
+        ids, am = encode_queries(self.texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
         self._ids, self._am = ids, am
         # default weights = the searcher's own defaults (target 1.0, cue 0.5, unknown 0.5;
         # interface_searcher.py:88-91,136); a searcher overrides them via set_class_weights
         w = [1.0] * len(target_objects) + [0.5] * len(cue_objects) + [0.5]
         self.scorer.set_queries(ids, am, w)
-        self._class_weight = np.asarray(w, dtype=np.float32)
+        self._class_weight = np.asarray(w, dtype=np.float64)
 
     def inference_detector(self, images, **kwargs) -> List[Detections]:
         import torch
@@ -141,7 +149,7 @@ class OWLInterface(HeuristicInterface):
         """Install ``object2weight.get(name, 0.5)`` per query (interface_searcher.py:136)."""
         w = [float(object2weight.get(t[0], 0.5)) for t in self.texts]
         self.scorer.set_class_weights(w)
-        self._class_weight = np.asarray(w, dtype=np.float32)
+        self._class_weight = np.asarray(w, dtype=np.float64)
 
     def score_batch(self, d_images, grid_rows: int, grid_cols: int, image_sets=None):
         """Batched scoring of device images u8 [B,H,W,3] -> tstar_amd.owl.ScoreResult (device tensors).
@@ -156,7 +164,7 @@ class OWLInterface(HeuristicInterface):
         if not 1 <= int(slot) <= 31:
             raise ValueError("install_queries: slot must be in 1..31")
         texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
-        ids, am = encode_queries(texts, self.model_name_or_path)
+        ids, am = encode_queries(texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
         o2w = dict(object2weight or {})
         for o in target_objects:
             o2w.setdefault(o, 1.0)

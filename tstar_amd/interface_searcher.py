@@ -5,8 +5,9 @@
   are one HIP kernel (tstar_frames_to_grid), verification frames another (tstar_frames_resize);
 * grid scoring and the detection -> grid-cell aggregation are tstar_owl_score;
 * the float64 searcher state (score_distribution, non_visiting_frames, P) lives on the device and
-  is updated by the tstar_searcher_* kernels; only the FITPACK smoothing-spline *fit*
-  (scipy.interpolate.UnivariateSpline, as the reference, :265) and the MT19937 draws
+  is updated by the tstar_searcher_* kernels; only the smoothing-spline distribution of the <= 1008
+  visited frames (scipy.interpolate.UnivariateSpline + numpy's exp, the reference's own calls,
+  :262-274 -- which makes P bit-identical to the reference's by construction) and the MT19937 draws
   (numpy legacy RandomState, as the reference's np.random.choice, :353,372) run on the host;
 * verification (:382-420) is batched speculatively: every candidate frame of an iteration is
   scored in one launch, then the reference's sequential ``remaining_targets`` logic is replayed on
@@ -23,9 +24,9 @@ import ctypes as C
 from typing import List, Optional, Tuple
 
 import numpy as np
-from scipy.interpolate import UnivariateSpline      # FITPACK fit on the host, as the reference (:265)
 
 from . import _lib
+from .spline_worker import spline_distribution      # FITPACK fit + sigmoid on the host, as the reference (:262-274)
 from .video import FrameStore, open_video
 
 CELL_W, CELL_H = 200, 95            # create_image_grid's hard-coded cell size (:186)
@@ -77,8 +78,34 @@ class _DeviceState:
                    "tstar_searcher_sampler_prep")
         return bool(fb.value)
 
-    def pop_prep(self):
-        _lib.check(self.lib.tstar_searcher_pop_prep(self.h, _lib.stream_ptr()), "tstar_searcher_pop_prep")
+    def pop_prep(self) -> Tuple[int, float]:
+        """-> (count_nonzero(p > 0), score.sum()) of the weights just prepared."""
+        nnz, tot = C.c_int(0), C.c_double(0.0)
+        _lib.check(self.lib.tstar_searcher_pop_prep(self.h, C.byref(nnz), C.byref(tot), _lib.stream_ptr()),
+                   "tstar_searcher_pop_prep")
+        return int(nnz.value), float(tot.value)
+
+    def window_spread(self, secs, confs, window: int):
+        s = np.ascontiguousarray(secs, dtype=np.int32)
+        c = np.ascontiguousarray(confs, dtype=np.float64)
+        if s.shape != c.shape or s.ndim != 1:
+            raise ValueError("window_spread: one confidence per sampled frame")
+        if len(s) == 0:
+            return
+        _lib.check(self.lib.tstar_searcher_window_spread(self.h, s.ctypes.data, c.ctypes.data, len(s), int(window),
+                                                         _lib.stream_ptr()), "tstar_searcher_window_spread")
+
+    def visited(self) -> Tuple[np.ndarray, np.ndarray]:
+        nv = C.c_int(0)
+        _lib.check(self.lib.tstar_searcher_visited(self.h, C.byref(nv), self._vx.ctypes.data, self._vy.ctypes.data,
+                                                   _lib.stream_ptr()), "tstar_searcher_visited")
+        return self._vx[:nv.value].copy(), self._vy[:nv.value].copy()
+
+    def write(self, which: int, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.shape != (self.N,):
+            raise ValueError(f"searcher state arrays have length {self.N}")
+        _lib.check(self.lib.tstar_searcher_write(self.h, int(which), v.ctypes.data, _lib.stream_ptr()), "tstar_searcher_write")
 
     def draw(self, x) -> np.ndarray:
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -108,6 +135,30 @@ class _DeviceState:
         out = np.empty(self.N, dtype=np.float64)
         _lib.check(self.lib.tstar_searcher_read(self.h, which, out.ctypes.data, _lib.stream_ptr()), "tstar_searcher_read")
         return out
+
+
+class _ResizedFrames:
+    """The second element of ``sample_frames``' return value: the sampled frames resized to (out_w, out_h) --
+    ``[cv2.resize(frame, (800, 380)) for frame in frames]`` in the reference (:362) -- materialised on first
+    access by the device resize kernel (tstar_frames_resize) and ONE device->host copy."""
+
+    def __init__(self, searcher, secs, out_w: int, out_h: int):
+        self.searcher, self.secs, self.out_w, self.out_h = searcher, [int(s) for s in secs], out_w, out_h
+        self._host = None
+
+    def _materialise(self) -> np.ndarray:
+        if self._host is None:
+            self._host = self.searcher._device_resized(self.secs, self.out_w, self.out_h).cpu().numpy()
+        return self._host
+
+    def __len__(self) -> int:
+        return len(self.secs)
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
 
 
 class TStarSearcher:
@@ -181,27 +232,46 @@ class TStarSearcher:
         self.iterations = 0
 
     # ---- state views (numpy copies of the device arrays, like the reference's attributes) -----
+    # Reading gives a fresh host copy; ASSIGNING (as a caller of the reference may: they are plain attributes
+    # there) uploads the array.  In-place edits of a copy do not reach the device -- assign it back.
     @property
     def score_distribution(self) -> np.ndarray:
         return self._state.read(0)
+
+    @score_distribution.setter
+    def score_distribution(self, values):
+        self._state.write(0, values)
 
     @property
     def non_visiting_frames(self) -> np.ndarray:
         return self._state.read(1)
 
+    @non_visiting_frames.setter
+    def non_visiting_frames(self, values):
+        self._state.write(1, values)
+
     @property
     def P(self) -> np.ndarray:
         return self._state.read(2)
+
+    @P.setter
+    def P(self, values):
+        self._state.write(2, values)
 
     # ---- helpers ---------------------------------------------------------------------------------
     def _uniform(self, k: int) -> np.ndarray:
         return (self._rng if self._rng is not None else np.random).random_sample(k)
 
-    def _choice(self, size: int) -> np.ndarray:
+    def _choice(self, size: int, nnz: Optional[int] = None, total: Optional[float] = None) -> np.ndarray:
         """numpy legacy RandomState.choice(N, size, replace=False, p) over the device cdf
-        (:353-358, :372): MT19937 doubles on the host, searchsorted on the device."""
+        (:353-358, :372): MT19937 doubles on the host, searchsorted on the device.  ``nnz`` / ``total``
+        (count of p > 0, the sum p was normalised by) feed numpy's own argument checks, in numpy's order."""
+        if total is not None and not (total == total and total != 0 and abs(total) != float("inf")):
+            raise ValueError("probabilities contain NaN")            # p = score / 0 (or / nan)
         if size > self.total_frame_num:                  # numpy's own check (mtrand choice, replace=False)
             raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        if nnz is not None and nnz < size:
+            raise ValueError("Fewer non-zero entries in p than size")
         found: List[int] = []
         while len(found) < size:
             x = self._uniform(size - len(found))
@@ -237,7 +307,9 @@ class TStarSearcher:
             for det in detections:
                 for box, label, conf in zip(det.xyxy, det.class_id, det.confidence):
                     name = self.heuristic.texts[label][0]
-                    adj = conf * self.object2weight.get(name, 0.5)
+                    # float64 product, as np.float32 * Python float is under the reference's pinned numpy 1.26
+                    # (and as cell_reduce_kernel forms it); equal to the float32 product for weights 1.0 / 0.5
+                    adj = float(conf) * float(self.object2weight.get(name, 0.5))
                     gx = min(int(((box[0] + box[2]) / 2) // grid_width), grid_cols - 1)
                     gy = min(int(((box[1] + box[3]) / 2) // grid_height), grid_rows - 1)
                     cmap[gy, gx] = max(cmap[gy, gx], adj)
@@ -264,6 +336,8 @@ class TStarSearcher:
         import torch
         if len(frames) != rows * cols:
             raise ValueError("Frame count does not match grid dimensions")      # :183-184
+        if isinstance(frames, _ResizedFrames) and frames.searcher is self and (rows, cols) == tuple(self.image_grid_shape):
+            return self._device_grid(frames.secs).cpu().numpy()                  # same bytes, no host round trip
         st = np.ascontiguousarray(np.stack([np.asarray(f, dtype=np.uint8) for f in frames]))
         if st.ndim != 4 or st.shape[3] != 3:
             raise ValueError("create_image_grid expects HxWx3 uint8 frames of one size")
@@ -290,16 +364,19 @@ class TStarSearcher:
                                                         _lib.stream_ptr()), "tstar_frames_to_grid")
         return grid
 
-    def _device_verify_frames(self, secs):
+    def _device_resized(self, secs, out_w: int, out_h: int):
         import torch
         N, H, Wd, _ = self.store.shape
-        out = torch.empty((len(secs), VERIFY_H, VERIFY_W, 3), dtype=torch.uint8, device=self.store.frames.device)
+        out = torch.empty((len(secs), out_h, out_w, 3), dtype=torch.uint8, device=self.store.frames.device)
         idx = self._d_idx(secs)
         _lib.check(self._state.lib.tstar_frames_resize(self.store.frames.data_ptr(), N, H, Wd, idx.data_ptr(), len(secs),
-                                                       VERIFY_W, VERIFY_H, out.data_ptr(), int(self.store.fmt == "nv12"),
+                                                       out_w, out_h, out.data_ptr(), int(self.store.fmt == "nv12"),
                                                        _lib.stream_ptr()),
                    "tstar_frames_resize")
         return out
+
+    def _device_verify_frames(self, secs):
+        return self._device_resized(secs, VERIFY_W, VERIFY_H)
 
     # ---- distribution ----------------------------------------------------------------------------
     def store_score_distribution(self):
@@ -318,11 +395,24 @@ class TStarSearcher:
         in the reference's order)."""
         vx, vy = self._state.apply_grid(secs, d_conf)
         ctx = overlap() if overlap is not None else None
-        spline = UnivariateSpline(vx, vy, s=0.5)                  # FITPACK fit on the host, as :265
-        t, c, k = spline._eval_args
-        self._state.set_spline(t, c, k)
+        # FITPACK fit, evaluation, sigmoid and normalisation on the host with the reference's own calls (:262-274)
+        self._state.write(2, spline_distribution(vx, vy, self.total_frame_num))
         self.store_score_distribution()
         return ctx
+
+    def update_top_25_with_window(self, frame_confidences, sampled_frame_indices, window_size: int = 5):
+        """(:215-241) raise the scores around the sampled frames whose confidence is in the top quartile of
+        ``frame_confidences``: in the given order and in place, ``score[f + o] = max(score[f + o], score[f] / (|o| + 1))``
+        for ``|o| <= window_size`` -- on the device score array (tstar_searcher_window_spread)."""
+        self._state.window_spread([int(i) for i in sampled_frame_indices], [float(c) for c in frame_confidences],
+                                  window_size)
+
+    def spline_keyframe_distribution(self, non_visiting_frames, score_distribution, video_length: int) -> np.ndarray:
+        """(:243-274) sampling distribution from the visited frames of the GIVEN arrays (it does not touch the
+        searcher's state; ``update_frame_distribution`` assigns the result to ``P``)."""
+        non_visiting_frames = np.asarray(non_visiting_frames)
+        visited = np.nonzero(non_visiting_frames == 0)[0]
+        return spline_distribution(visited, np.asarray(score_distribution, dtype=np.float64)[visited], int(video_length))
 
     def update_frame_distribution(self, sampled_frame_indices, confidence_maps, detected_objects_maps):
         """(:276-321) public form over host arrays: cell (i // cols, i % cols) of ``confidence_maps[0]`` belongs to the
@@ -341,8 +431,14 @@ class TStarSearcher:
 
     # ---- sampling --------------------------------------------------------------------------------
     def sample_frames(self, num_samples: int):
-        """(:324-363) returns (seconds in draw order, device grid-ready frame indices).  The resized
-        frames themselves are produced on the device by ``_device_grid``."""
+        """(:324-363) returns ``(sampled seconds in draw order, their frames resized to 800x380)`` like the
+        reference.  The frames are a lazy sequence (``_ResizedFrames``): ``search()`` builds its grid straight from
+        the resident store and never materialises them; a caller that indexes or iterates them gets uint8
+        [380,800,3] arrays produced by the device resize kernel with one device->host copy."""
+        secs = self._sample_secs(num_samples)
+        return secs, _ResizedFrames(self, secs, CELL_W * 4, CELL_H * 4)
+
+    def _sample_secs(self, num_samples: int) -> List[int]:
         if num_samples > self.total_frame_num:
             num_samples = self.total_frame_num
         if not self.Score_history:
@@ -357,9 +453,11 @@ class TStarSearcher:
         return [int(s) for s in secs]
 
     def pop_frames(self, video_path, num_samples: int):
-        """(:365-380) weighted random sample of K seconds from score_distribution, sorted."""
-        self._state.pop_prep()
-        secs = self._choice(num_samples)
+        """(:365-380) weighted random sample of K seconds from score_distribution, sorted.  Raises what
+        ``np.random.choice`` raises in the reference when fewer than K scores are non-zero (short videos under
+        ``search_budget=1.0``: every frame visited, most cells empty)."""
+        nnz, total = self._state.pop_prep()
+        secs = self._choice(num_samples, nnz, total)
         secs.sort()
         time_stamps = [sec / self.fps for sec in secs]
         frames = self.store.host_frames(secs)
@@ -476,7 +574,8 @@ class TStarSearcher:
         while self.remaining_targets and self.search_budget > 0:
             rows, cols = self.image_grid_shape
             n = rows * cols
-            secs = self.sample_frames(n)
+            secs, _lazy_frames = self.sample_frames(n)       # the reference's call (wrappers / subclasses see it)
+            secs = [int(s_) for s_ in secs]
             self.search_budget -= n
             grid = self._device_grid(secs)
             if self._fast:

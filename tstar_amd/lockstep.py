@@ -54,7 +54,7 @@ def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray
     while act:
         secs_l, grids = [], []
         for s in act:
-            secs = s.sample_frames(n)
+            secs = s._sample_secs(n)
             s.search_budget -= n
             secs_l.append(secs)
             grids.append(s._device_grid(secs))
@@ -82,10 +82,10 @@ def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray
                                  for i, s in enumerate(act) if cand_l[i]])
             sets = [s._slot for i, s in enumerate(act) for _ in cand_l[i]]
             vres = h.score_batch(vframes, 1, 1, image_sets=sets)
-        # ... while the host fits the smoothing splines (FITPACK, as interface_searcher.py:265): one worker
-        # process per item (tstar_amd.spline_pool), same scipy call, bit-identical coefficients
-        for s, (t, c, k) in zip(act, spline_pool.fit_many(fits, s=0.5)):
-            s._state.set_spline(t, c, k)
+        # ... while the host builds the sampling distributions (FITPACK fit + sigmoid, interface_searcher.py:262-274):
+        # one worker process per item (tstar_amd.spline_pool), same scipy / numpy calls, bit-identical P
+        for s, P in zip(act, spline_pool.distribution_many(fits, [a.total_frame_num for a in act], s=0.5)):
+            s._state.write(2, P)
         for s in act:
             s.store_score_distribution()
         if vres is not None:

@@ -104,7 +104,7 @@ class OwlScorer:
     def set_queries(self, input_ids: np.ndarray, attention_mask: np.ndarray, class_weight: Sequence[float], slot: int = 0):
         ids = np.ascontiguousarray(input_ids, dtype=np.int32)
         am = np.ascontiguousarray(attention_mask, dtype=np.int32)
-        w = np.ascontiguousarray(class_weight, dtype=np.float32)
+        w = np.ascontiguousarray(class_weight, dtype=np.float64)
         Q = ids.shape[0]
         if ids.shape != (Q, W.T_LEN) or am.shape != ids.shape or w.shape != (Q,):
             raise ValueError("set_queries: ids/mask must be [Q,16] and class_weight [Q]")
@@ -116,7 +116,7 @@ class OwlScorer:
     def set_query_embeds(self, embeds: np.ndarray, query_mask: Sequence[int], class_weight: Sequence[float], slot: int = 0):
         e = np.ascontiguousarray(embeds, dtype=np.float32)
         m = np.ascontiguousarray(query_mask, dtype=np.uint8)
-        w = np.ascontiguousarray(class_weight, dtype=np.float32)
+        w = np.ascontiguousarray(class_weight, dtype=np.float64)
         Q = e.shape[0]
         if e.shape != (Q, W.PROJ) or m.shape != (Q,) or w.shape != (Q,):
             raise ValueError("set_query_embeds: embeds [Q,512], mask [Q], class_weight [Q]")
@@ -126,7 +126,7 @@ class OwlScorer:
         self.Qs[int(slot)] = Q
 
     def set_class_weights(self, class_weight: Sequence[float], slot: int = 0):
-        w = np.ascontiguousarray(class_weight, dtype=np.float32)
+        w = np.ascontiguousarray(class_weight, dtype=np.float64)
         if w.shape != (self.Qs.get(int(slot), 0),):
             raise ValueError("set_class_weights: one weight per installed query")
         rc = self._lib.tstar_owl_set_class_weights(self._h, int(slot), w.ctypes.data, len(w), _lib.stream_ptr())

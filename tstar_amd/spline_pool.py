@@ -71,31 +71,39 @@ class SplinePool:
         self._procs = []
 
     @staticmethod
-    def _send(p: subprocess.Popen, x: np.ndarray, y: np.ndarray, s: float):
+    def _send(p: subprocess.Popen, x: np.ndarray, y: np.ndarray, s: float, n_frames: int = 0):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64)
         if x.shape != y.shape or x.ndim != 1:
             raise ValueError("spline fit needs two 1-D arrays of equal length")
-        p.stdin.write(struct.pack("<qd", len(x), float(s)) + x.tobytes() + y.tobytes())
+        p.stdin.write(struct.pack("<qdq", len(x), float(s), int(n_frames)) + x.tobytes() + y.tobytes())
         p.stdin.flush()
 
     @staticmethod
-    def _recv(p: subprocess.Popen) -> Tuple[np.ndarray, np.ndarray, int]:
+    def _recv(p: subprocess.Popen):
         hdr = p.stdout.read(24)
         if len(hdr) != 24:
             raise SplinePoolError("spline worker exited")
-        status, n, k = struct.unpack("<qqq", hdr)
+        status, nbytes, k = struct.unpack("<qqq", hdr)
         if status != 0:
-            raise SplinePoolError("spline worker: " + p.stdout.read(n).decode(errors="replace"))
-        buf = p.stdout.read(16 * n)
-        if len(buf) != 16 * n:
+            raise SplinePoolError("spline worker: " + p.stdout.read(nbytes).decode(errors="replace"))
+        buf = p.stdout.read(nbytes)
+        if len(buf) != nbytes:
             raise SplinePoolError("spline worker exited mid-reply")
+        if k < 0:                                   # a distribution P[N]
+            return np.frombuffer(buf, dtype=np.float64).copy()
+        n = nbytes // 16
         t = np.frombuffer(buf, dtype=np.float64, count=n).copy()
         c = np.frombuffer(buf, dtype=np.float64, count=n, offset=8 * n).copy()
         return t, c, int(k)
 
-    def fit_many(self, problems: Sequence[Tuple[np.ndarray, np.ndarray]], s: float = 0.5):
-        """[(x, y)] -> [(t, c, k)] with c zero-padded to len(t) (FITPACK's own layout), input order."""
+    def fit_many(self, problems: Sequence[Tuple[np.ndarray, np.ndarray]], s: float = 0.5, n_frames=0):
+        """[(x, y)] -> [(t, c, k)] with c zero-padded to len(t) (FITPACK's own layout), input order; with
+        ``n_frames`` > 0 (one int, or one per problem) -> [P float64 [n_frames]]
+        (spline_worker.spline_distribution) instead."""
+        nf = list(n_frames) if hasattr(n_frames, "__len__") else [int(n_frames)] * len(problems)
+        if len(nf) != len(problems):
+            raise ValueError("fit_many: one n_frames per problem")
         if not self._procs:
             raise SplinePoolError("spline pool is closed")
         out: List[Optional[Tuple[np.ndarray, np.ndarray, int]]] = [None] * len(problems)
@@ -106,8 +114,8 @@ class SplinePool:
             try:
                 for lo in range(0, len(problems), w):
                     chunk = problems[lo:lo + w]
-                    for p, (x, y) in zip(self._procs, chunk):
-                        self._send(p, x, y, s)
+                    for j, (p, (x, y)) in enumerate(zip(self._procs, chunk)):
+                        self._send(p, x, y, s, nf[lo + j])
                     for j, p in enumerate(self._procs[:len(chunk)]):
                         out[lo + j] = self._recv(p)
             except (OSError, SplinePoolError):
@@ -140,17 +148,38 @@ def get_pool() -> Optional[SplinePool]:
     return _pool
 
 
-def fit_many(problems: Sequence[Tuple[np.ndarray, np.ndarray]], s: float = 0.5):
-    """Fit every (x, y) with ``UnivariateSpline(x, y, s=s)``: in the worker pool when there is more than one
-    problem and a pool is available, otherwise in-process.  Returns [(t, c, k)] in input order."""
+def _pooled(problems, s: float, n_frames):
     global _pool_failed
     if len(problems) > 1:
         pool = get_pool()
         if pool is not None:
             try:
-                return pool.fit_many(problems, s)
+                return pool.fit_many(problems, s, n_frames)
             except (OSError, SplinePoolError) as e:
                 _pool_failed = True
                 print(f"tstar_amd: spline pool failed ({e}); fitting in-process", file=sys.stderr)
+    return None
+
+
+def fit_many(problems: Sequence[Tuple[np.ndarray, np.ndarray]], s: float = 0.5):
+    """Fit every (x, y) with ``UnivariateSpline(x, y, s=s)``: in the worker pool when there is more than one
+    problem and a pool is available, otherwise in-process.  Returns [(t, c, k)] in input order."""
+    out = _pooled(problems, s, 0)
+    if out is not None:
+        return out
     from scipy.interpolate import UnivariateSpline
     return [UnivariateSpline(x, y, s=s)._eval_args for x, y in problems]
+
+
+def distribution_many(problems: Sequence[Tuple[np.ndarray, np.ndarray]], n_frames: Sequence[int], s: float = 0.5):
+    """The sampling distribution P (float64 [n_frames[i]]) of every (visited frames, scores) problem --
+    spline_worker.spline_distribution, i.e. interface_searcher.py:262-274 -- in the worker pool when there is
+    more than one problem and a pool is available, otherwise in-process (same statements, same libraries)."""
+    nf = [int(n) for n in n_frames]
+    if len(nf) != len(problems) or any(n < 1 for n in nf):
+        raise ValueError("distribution_many: one positive n_frames per problem")
+    out = _pooled(problems, s, nf)
+    if out is not None:
+        return out
+    from .spline_worker import spline_distribution
+    return [spline_distribution(x, y, n, s) for (x, y), n in zip(problems, nf)]
