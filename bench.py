@@ -7,9 +7,11 @@ One "step" = one complete keyframe search (TStarSearcher.search(): iterative sam
 scoring, verification, distribution updates, final K=8 keyframes) over one 3600-frame
 synthetic video that is already resident in HBM -- BASELINE.json configs[1]: "Same single
 video on 1xMI355X, HIP OWL-ViT-B/32 scorer, batch=256 frames/iter" (grid 16x16).  With N > 1
-(torch.distributed, one rank per GPU, RCCL) every rank searches its own stream of independent
-(video, question) items (weak scaling, no data-path collective) and the final keyframe indices
-are all-gathered once inside the timed region.  Within a rank, items advance in
+(torch.distributed, one rank per GPU, RCCL) the workload is BASELINE configs[2]'s shape: every
+step is its own (video, question) item -- a distinct procedural video, one of four questions --
+item i on rank i % N (weak scaling, no data-path collective), and the final keyframe indices are
+all-gathered once inside the timed region through the library's own RCCL entry point
+(tstar_allgather_i32).  --workload haystack32 runs exactly configs[2] (32 items).  Within a rank, items advance in
 lock-step groups of --lockstep (default 4): iteration t of every item of the group shares one
 detector batch, each image scored against its own question (tstar_amd/lockstep.py); results are
 bit-identical to one-by-one searches.
@@ -39,6 +41,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA peak (same guide)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 N_FRAMES, FRAME_H, FRAME_W = 3600, 360, 640
 TARGETS, CUES = ["couch"], ["tv", "chair"]
+# questions of the haystack workload (BASELINE configs[2]: independent (video, question) items); item i asks QUESTIONS[i % 4]
+QUESTIONS = [(["couch"], ["tv", "chair"]), (["dog"], ["leash", "park bench"]), (["red car"], ["road"]),
+             (["laptop", "mug"], ["desk"])]
 
 
 def parse():
@@ -61,26 +66,63 @@ def parse():
     ap.add_argument("--lockstep", type=int, default=4,
                     help="independent (video, question) items advanced in lock-step per detector batch "
                          "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time")
+    ap.add_argument("--workload", choices=["auto", "single", "haystack", "haystack32"], default="auto",
+                    help="single = BASELINE configs[1]: every step searches the SAME resident video with its own sampler seed; "
+                         "haystack = configs[2] shape: every step is its own (video, question) item -- a distinct procedural "
+                         "video and one of 4 questions, item i on rank i %% world, --steps items per rank (weak scaling); "
+                         "haystack32 = exactly configs[2]: 32 items in total over the ranks (--steps is ignored); "
+                         "auto = single on 1 GPU, haystack on more")
+    ap.add_argument("--questions", choices=["auto", "same", "cycle"], default="auto",
+                    help="haystack items ask: same = the configs[1] question for every item (per-item work as in `single`, so "
+                         "the 1/2/4/8-GPU weak-scaling points are comparable); cycle = 4 different questions (several query sets "
+                         "resident, 1-2 targets each; with the synthetic weights most cells then list a target and 3-4x more frames "
+                         "go through verification); auto = same for haystack, cycle for haystack32")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run oracle replay of step 0's keyframes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
 
 
-def make_searcher(heuristic, store, g, seed, k=8):
+def make_searcher(heuristic, item, g, k=8):
+    """``item``: dict(store=FrameStore, targets=, cues=, seed=sampler seed)."""
     from tstar_amd.interface_searcher import TStarSearcher
-    return TStarSearcher(store, heuristic, list(TARGETS), list(CUES), search_nframes=k, image_grid_shape=(g, g),
-                         search_budget=1000, confidence_threshold=0.6, rng=np.random.RandomState(seed),
-                         keep_visual_history=False)
+    return TStarSearcher(video_path=item["store"], heuristic=heuristic, target_objects=list(item["targets"]),
+                         cue_objects=list(item["cues"]), search_nframes=k, image_grid_shape=(g, g), search_budget=1000,
+                         confidence_threshold=0.6, rng=np.random.RandomState(item["seed"]), keep_visual_history=False)
 
 
-def run_group(heuristic, store, g, seeds, k=8):
-    """One lock-step group of independent searches (a single search when len(seeds) == 1)."""
+def run_group(heuristic, items, g, k=8):
+    """One lock-step group of independent (video, question) searches (a single search when len(items) == 1)."""
     from tstar_amd.lockstep import search_lockstep
-    ss = [make_searcher(heuristic, store, g, sd, k) for sd in seeds]
+    ss = [make_searcher(heuristic, it, g, k) for it in items]
     if len(ss) == 1:
         return [(ss[0], ss[0].search()[1])]
     res = search_lockstep(ss)
     return [(s_, r[1]) for s_, r in zip(ss, res)]
+
+
+def verify_keyframes(heuristic, item, g, k, timed_keyframes):
+    """Post-run check (outside the timed region): item 0 of rank 0 is searched once more ALONE with a recorder on the
+    scorer; its keyframes must equal the ones the timed (lock-step) run produced, and the recorded confidences replayed
+    through the CPU oracle searcher (oracle/replay.py: the reference's loop restated, pinned by goldens) must yield the
+    same sampled seconds and the same keyframes.  Returns (verified, detail)."""
+    from oracle import replay
+    rec = replay.Recorder(heuristic, keep_images=False)
+    try:
+        s = make_searcher(heuristic, item, g, k)
+        log = []
+        orig = s.sample_frames
+        s.sample_frames = lambda num: (lambda r: (log.append(list(r[0])), r)[1])(orig(num))
+        _, ts = s.search()
+    finally:
+        rec.restore()
+    solo = [int(t) for t in ts]
+    ref, ts_ref = replay.replay_through_oracle(rec.calls, heuristic.texts, item["targets"], item["cues"], s.total_frame_num, g, k,
+                                               1000, 0.6, item["seed"])
+    ok = (solo == list(timed_keyframes) and [int(t) for t in ts_ref] == solo and [it["secs"] for it in ref.trace] == log
+          and np.array_equal(s.score_distribution, ref.score))
+    return ok, {"timed": list(timed_keyframes), "solo_rerun": solo, "oracle_replay": [int(t) for t in ts_ref],
+                "iterations": len(log), "verification_calls": int(sum(len(it["verify"]) for it in ref.trace))}
 
 
 def cpu_baseline(args, stats):
@@ -180,7 +222,12 @@ def main():
     args = parse()
     # the searcher prints progress like the reference ("Found target ...", sampler warnings): keep stdout
     # clean for the ONE JSON line
-    real_stdout = sys.stdout
+    # ... and at the file-descriptor level too: RCCL prints a version banner and gloo its connection notes with C stdio
+    # straight to fd 1, which would land next to the JSON line
+    sys.stdout.flush()
+    real_fd = os.dup(1)
+    os.dup2(2, 1)
+    real_stdout = os.fdopen(real_fd, "w")
     sys.stdout = sys.stderr
     import torch
     import torch.distributed as dist
@@ -204,7 +251,7 @@ def main():
 
     from tstar_amd import _lib
     from tstar_amd.interface_heuristic import OWLInterface
-    from tstar_amd.sharding import gather_keyframes
+    from tstar_amd.sharding import close_comm, gather_keyframes, interleave_by_item
     from tstar_amd.video import synthetic_video
     lib = _lib.load()
 
@@ -214,8 +261,25 @@ def main():
     heuristics = [OWLInterface(synthetic_seed=0, max_batch=args.max_batch, device=f"cuda:{local_rank}",
                                weights_dtype=args.weights) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
-    store = synthetic_video(args.nframes, FRAME_H, FRAME_W, seed=0)
     g = args.grid
+    workload = args.workload
+    if workload == "auto":
+        workload = "single" if world == 1 else "haystack"
+    if workload == "haystack32":
+        args.steps = (32 - rank + world - 1) // world            # item i -> rank i % world; 32 items in total
+        n_items_total = 32
+    else:
+        n_items_total = args.steps * world
+    shared_store = synthetic_video(args.nframes, FRAME_H, FRAME_W, seed=0) if workload == "single" else None
+    cycle_questions = args.questions == "cycle" or (args.questions == "auto" and workload == "haystack32")
+
+    def make_item(item_id, sampler_seed, store_seed=None):
+        """One (video, question) item; its decoded video is built in HBM here, before any timed region."""
+        if workload == "single":
+            return dict(id=item_id, store=shared_store, targets=TARGETS, cues=CUES, seed=sampler_seed)
+        t_, c_ = QUESTIONS[item_id % len(QUESTIONS)] if cycle_questions else (TARGETS, CUES)
+        return dict(id=item_id, store=synthetic_video(args.nframes, FRAME_H, FRAME_W, seed=1000 + (item_id if store_seed is None else store_seed)),
+                    targets=t_, cues=c_, seed=sampler_seed)
 
     def barrier():
         torch.cuda.synchronize()
@@ -223,13 +287,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_many(seeds):
-        """Run one search per seed, `conc` at a time; returns per-search (searcher, timestamps, seconds)."""
+    def run_many(items):
+        """Run one search per item, `conc` lock-step groups at a time; returns per-search (searcher, timestamps, seconds)."""
         q = queue.Queue()
         L = max(1, min(args.lockstep, 31))
-        for i in range(0, len(seeds), L):
-            q.put((i, seeds[i:i + L]))
-        out = [None] * len(seeds)
+        for i in range(0, len(items), L):
+            q.put((i, items[i:i + L]))
+        out = [None] * len(items)
         errs = []
 
         def worker(w):
@@ -242,7 +306,7 @@ def main():
                         except queue.Empty:
                             break
                         t1 = time.perf_counter()
-                        grp = run_group(heuristics[w], store, g, sd, args.search_nframes)
+                        grp = run_group(heuristics[w], sd, g, args.search_nframes)
                         streams[w].synchronize()
                         for j, (s_, ts_) in enumerate(grp):
                             out[i + j] = (s_, ts_, time.perf_counter() - t1)
@@ -262,28 +326,37 @@ def main():
     # untimed warm-up: at least one FULL lock-step group, so the timed region meets no first-use cost
     # (kernel attributes, resample tables, workspace growth) at its own batch sizes
     n_warm = 0 if args.warmup <= 0 else max(args.warmup, min(args.lockstep, 31) * conc)
-    run_many([10_000 + rank * 1000 + w for w in range(n_warm)])
+    # this rank's timed items: item id k * world + rank (item i -> rank i % world); the sampler seed is a function of the
+    # item id only, so results do not depend on the rank count.  Videos are resident in HBM before the timer starts.
+    items = [make_item(k * world + rank, 2025 + k * world + rank) for k in range(args.steps)]
+    warm_items = [dict(items[w % len(items)], seed=10_000 + rank * 1000 + w) for w in range(n_warm)] if items else []
+    run_many(warm_items)
     # latency of ONE search running alone (the "sec/video to 8 keyframes" half of the metric, untimed):
     solo_latency = None
-    if n_warm > 0:
+    if n_warm > 0 and items:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        run_group(heuristics[0], store, g, [20_000 + rank], args.search_nframes)
+        run_group(heuristics[0], [dict(items[0], seed=20_000 + rank)], g, args.search_nframes)
         torch.cuda.synchronize()
         solo_latency = time.perf_counter() - t1
+    if world > 1:                      # create the library's RCCL communicator before the timer (a one-off, like NCCL init)
+        gather_keyframes([[0]], world)
     barrier()
     # time every 5th GEMM / attention launch with HIP event pairs (5 is co-prime with the 4-GEMM layer
     # pattern and the 52-GEMM forward, so every shape is sampled evenly); timing all of them costs 2.2 %
     _lib.check(lib.tstar_prof_enable(0 if os.environ.get('TSTAR_BENCH_NO_PROF') else PROF_STRIDE))
     t0 = time.perf_counter()
-    res = run_many([2025 + rank * args.steps + k for k in range(args.steps)])
+    res = run_many(items)
     frames = sum(r[0].frames_scored for r in res)
     grid_calls = sum(r[0].iterations for r in res)
     verify_calls = sum(r[0].detector_calls - r[0].iterations for r in res)
     images = sum(r[0].device_images_scored for r in res)
     keys = [[int(t) for t in r[1]] for r in res]
-    latency = sum(r[2] for r in res) / len(res)
-    all_keys = gather_keyframes(keys, world)            # RCCL all-gather of the keyframe indices (N > 1)
+    latency = sum(r[2] for r in res) / max(len(res), 1)
+    # RCCL all-gather of the keyframe indices (N > 1), rows back in item order
+    all_keys = gather_keyframes(keys, world, pad_to=(n_items_total + world - 1) // world)
+    if world > 1:
+        all_keys = interleave_by_item(all_keys, n_items_total, world)
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(frames), float(images)], dtype=torch.float64, device=cdev)
@@ -320,6 +393,23 @@ def main():
         gemm_kernel, peak, exec_mult = f"gemm_f32_kernel<WMODE={1 if args.weights == 'bf16' else 2}> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
     else:
         gemm_kernel, peak, exec_mult = "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1.0
+    # post-run parity check of the keyframes this run produced (rank 0, step 0): solo re-run + oracle replay, untimed
+    verified, verify_detail = None, None
+    if rank == 0 and not args.no_verify and items:
+        verified, verify_detail = verify_keyframes(heuristics[0], items[0], g, args.search_nframes, keys[0])
+    wl_name = {"single": "configs[1]", "haystack": "configs[2] shape (weak scaling: --steps items per rank)",
+               "haystack32": "configs[2]"}[workload]
+    if args.weights != "f32" or args.nframes != N_FRAMES:
+        wl_name = "variant of " + wl_name
+    if workload == "single":
+        wl_what = (f"ONE {args.nframes}-frame {FRAME_H}x{FRAME_W} synthetic RGB video resident in HBM, 1 question (targets {TARGETS}, "
+                   f"cues {CUES}), every step = one full search of it with its own sampler seed")
+    else:
+        wl_what = (f"{n_items_total} independent (video, question) items, item i on rank i % {world}: each its own {args.nframes}-frame "
+                   f"{FRAME_H}x{FRAME_W} procedural RGB video resident in HBM (seed 1000 + i) and "
+                   + (f"one of {len(QUESTIONS)} questions, cycled ({'; '.join('/'.join(t) + ' | ' + '/'.join(c) for t, c in QUESTIONS)})"
+                      if cycle_questions else f"the configs[1] question (targets {TARGETS}, cues {CUES})")
+                   + "; every step = one item's full search")
     if rank == 0:
         out = {
             "metric": "candidate frames scored/sec (whole node) + sec/video to 8 keyframes, 1h@1fps",
@@ -330,14 +420,15 @@ def main():
             "data": "synthetic",
             "config": {
                 "collective_backend": (backend if world > 1 else None),
-                "workload": f"{'configs[1]' if args.weights == 'f32' and args.nframes == N_FRAMES else 'variant'}: {args.nframes}-frame {FRAME_H}x{FRAME_W} synthetic RGB video resident in HBM, 1 question "
-                            f"(targets {TARGETS}, cues {CUES}), OWL-ViT-B/32 {args.weights} weights (seeded synthetic), grid {g}x{g} = "
+                "workload": f"{wl_name}: {wl_what}; OWL-ViT-B/32 {args.weights} weights (seeded synthetic), grid {g}x{g} = "
                             f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
+                "workload_kind": workload, "items_total": n_items_total,
                 "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc, "lockstep_items_per_batch": max(1, min(args.lockstep, 31)),
                 "mean_search_latency_sec": latency, "single_search_alone_latency_sec": solo_latency,
                 "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,
                 "detector_images_per_video": images / args.steps, "max_batch": args.max_batch,
                 "keyframes_rank0_step0": keys[0], "gathered_keyframe_rows": len(all_keys),
+                "keyframes_verified": verified, "keyframes_verification": verify_detail,
             },
             "roofline": {
                 "kernel": gemm_kernel, "bound": "mfma", "achieved": achieved * exec_mult,
@@ -359,6 +450,7 @@ def main():
         print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
+        close_comm()
         dist.destroy_process_group()
 
 

@@ -190,6 +190,23 @@ int tstar_searcher_write(tstar_searcher* s, int which, const double* h_in, void*
 /* copy a state array to the host: 0 score, 1 non_visiting, 2 P, 3 sampler p, 4 cdf.  Synchronises. */
 int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* stream);
 
+/* ------------------------------------------------------------------ multi-GPU
+ * The path shards over independent (video, question) items with no data-path collective; the ONE exchange is an
+ * all-gather of every rank's final keyframe indices -- what the sequential loop of
+ * LVHaystackBench/run_TStar_onDataset.py:195-205 accumulates in `results`.  One process per GPU; RCCL over xGMI.
+ * Bootstrap like NCCL's: rank 0 calls tstar_comm_unique_id and hands the TSTAR_COMM_ID_BYTES bytes to every rank by
+ * any out-of-band channel (a file, a TCP store, MPI, torch.distributed's store); then EVERY rank calls
+ * tstar_comm_create (collective; binds the current HIP device).  RCCL is dlopen'ed on first use (the copy a host
+ * such as PyTorch-ROCm already carries is reused); TSTAR_RCCL_LIB overrides the library name. */
+#define TSTAR_COMM_ID_BYTES 128
+typedef struct tstar_comm tstar_comm;
+int tstar_comm_unique_id(void* h_id /* TSTAR_COMM_ID_BYTES bytes */);
+int tstar_comm_create(tstar_comm** out, const void* h_id, int world, int rank);
+int tstar_comm_destroy(tstar_comm* c);
+/* d_recv int32 [world * count] = concatenation over ranks (rank order) of every rank's d_send int32 [count] (both on
+ * the device; pad short rows with -1).  Enqueued on `stream`; does not synchronise. */
+int tstar_allgather_i32(tstar_comm* c, const int32_t* d_send, int32_t* d_recv, int count, void* stream);
+
 /* ------------------------------------------------------------------ downstream selection (8f)
  * Replaces the score-based branch of extract_frames (LVHaystackBench/val_qa_results.py:90-110): the k
  * highest-probability seconds of a per-second distribution d_P f64 [N] (device) inside

@@ -131,6 +131,73 @@ def test_sharded_gather_world2_gloo(tmp_path):
     assert all("ok" in o for o in outs)
 
 
+_WORKER4 = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from tstar_amd.sharding import run_sharded, shard_items, item_seed
+rank, world = int(sys.argv[3]), 4
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
+# 10 items over 4 ranks: ranks 0,1 own 3 items, ranks 2,3 own 2 (uneven shards -> padded rows); K differs per item too
+def search(i):
+    return [item_seed(2025, i)] + list(range(i % 3 + 1))
+res = run_sharded(10, search, world, rank)
+assert res == [search(i) for i in range(10)], res
+assert shard_items(10, world, rank) == list(range(rank, 10, world))
+# fewer items than ranks: ranks 2 and 3 own nothing
+res = run_sharded(2, search, world, rank)
+assert res == [search(0), search(1)], res
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_sharded_gather_world4_uneven_gloo(tmp_path):
+    """BASELINE configs[2] shape on CPU: 10 items round-robin over 4 ranks (3/3/2/2), rows of different length, and
+    the fewer-items-than-ranks case, through run_sharded's one all-gather (gloo here, RCCL on GPUs)."""
+    script = tmp_path / "w4.py"
+    script.write_text(_WORKER4)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(4)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
+
+
+def test_spline_pool_distribution_matches_reference_statements(monkeypatch):
+    """lock-step groups get their sampling distributions P from the worker pool: bit-identical to the in-process
+    statements (tstar_amd.spline_worker.spline_distribution = interface_searcher.py:262-274) and to the oracle,
+    for items of DIFFERENT video lengths in one call."""
+    from oracle import searcher_ref as S
+    from tstar_amd import spline_pool
+    from tstar_amd.spline_worker import spline_distribution
+    probs, lens = [], [600, 1200, 350]
+    for seed, N in enumerate(lens):
+        rs = np.random.RandomState(seed)
+        vis = np.sort(rs.choice(N, 40, replace=False))
+        probs.append((vis.astype(np.int32), rs.rand(40) ** 4))
+    pool = spline_pool.SplinePool(2)
+    try:
+        got = pool.fit_many(probs, s=0.5, n_frames=lens)
+    finally:
+        pool.close()
+    for (x, y), N, P in zip(probs, lens, got):
+        unv = np.ones(N)
+        unv[x] = 0
+        sc = np.zeros(N)
+        sc[x] = y
+        assert P.shape == (N,) and np.array_equal(P, spline_distribution(x, y, N)) and np.array_equal(P, S.spline_distribution(unv, sc))
+    assert np.array_equal(spline_distribution(np.array([], int), np.array([]), 7), np.ones(7) / 7)
+    monkeypatch.setenv("TSTAR_SPLINE_WORKERS", "0")
+    monkeypatch.setattr(spline_pool, "_pool", None)
+    monkeypatch.setattr(spline_pool, "_pool_failed", False)
+    same = spline_pool.distribution_many(probs, lens)
+    assert all(np.array_equal(a, b) for a, b in zip(same, got))
+    with pytest.raises(ValueError):
+        spline_pool.distribution_many(probs, lens[:2])
+
+
 def test_spline_pool_matches_in_process_fit(monkeypatch):
     """The lock-step host path fits each item's smoothing spline in a worker process: (t, c, k) must be
     bit-identical to the in-process ``UnivariateSpline(x, y, s=0.5)`` the reference calls

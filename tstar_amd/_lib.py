@@ -50,6 +50,10 @@ SIGNATURES = {
     "tstar_searcher_set_scores": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tstar_searcher_read_state": (_i, [_vp, _vp, _vp]),
     "tstar_searcher_read": (_i, [_vp, _i, _vp, _vp]),
+    "tstar_comm_unique_id": (_i, [_vp]),
+    "tstar_comm_create": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+    "tstar_comm_destroy": (_i, [_vp]),
+    "tstar_allgather_i32": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tstar_topk_seconds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "tstar_ssim_pairwise": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tstar_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

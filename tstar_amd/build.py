@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     need_link = force or jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
     if need_link:
-        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -11,7 +11,57 @@ latency-bound.
 """
 from __future__ import annotations
 
+import ctypes as C
+import sys
 from typing import Callable, List, Sequence
+
+_COMM = None            # this process' tstar_comm handle (RCCL communicator created through the C ABI), or False = unavailable
+
+
+def _tstar_comm(world: int, rank: int):
+    """The library's own RCCL communicator (include/tstar_hip.h: tstar_comm_*), bootstrapped over the already
+    initialised torch.distributed group: rank 0 draws the unique id, the id is broadcast, every rank joins.  Returns
+    the handle, or None when RCCL could not be bound (the caller then gathers through torch.distributed, which is
+    RCCL as well)."""
+    global _COMM
+    if _COMM is not None:
+        return _COMM or None
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    lib = _lib.load()
+    idbuf = C.create_string_buffer(128)
+    box = [None]
+    if rank == 0:
+        box[0] = bytes(idbuf.raw) if lib.tstar_comm_unique_id(idbuf) == 0 else None
+        if box[0] is None:
+            print(f"tstar_amd: {lib.tstar_last_error().decode()}; gathering through torch.distributed", file=sys.stderr)
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        _COMM = False
+        return None
+    h = C.c_void_p()
+    ok = lib.tstar_comm_create(C.byref(h), box[0], world, rank) == 0
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if ok:
+            lib.tstar_comm_destroy(h)
+        elif rank == 0:
+            print(f"tstar_amd: {lib.tstar_last_error().decode()}; gathering through torch.distributed", file=sys.stderr)
+        _COMM = False
+        return None
+    _COMM = h
+    return h
+
+
+def close_comm():
+    """Destroy the library's communicator (before torch.distributed.destroy_process_group)."""
+    global _COMM
+    if _COMM:
+        from . import _lib
+        _lib.load().tstar_comm_destroy(_COMM)
+    _COMM = None
 
 
 
@@ -43,11 +93,20 @@ def gather_keyframes(local_rows: Sequence[Sequence[int]], world: int, pad_to: in
     nrow, k = int(shape[0]), int(shape[1])
     if pad_to is not None:
         nrow = max(nrow, pad_to)
-    buf = torch.full((nrow, k), -1, dtype=torch.int32, device=dev)
+    host = torch.full((nrow, k), -1, dtype=torch.int32)
     for i, r in enumerate(rows):
-        buf[i, :len(r)] = torch.tensor(r, dtype=torch.int32, device=dev)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
+        host[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+    buf = host.to(dev)
+    comm = _tstar_comm(world, dist.get_rank()) if on_gpu and nrow * k > 0 else None
+    if comm is not None:                         # the C-ABI entry a non-Python host would call: ncclAllGather on our stream
+        from . import _lib
+        flat = torch.empty((world, nrow, k), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().tstar_allgather_i32(comm, buf.data_ptr(), flat.data_ptr(), nrow * k, _lib.stream_ptr()),
+                   "tstar_allgather_i32")
+        out = list(flat.cpu())                   # synchronises the stream
+    else:
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
     res: List[List[int]] = []
     for t in out:
         for row in t.cpu().numpy():
