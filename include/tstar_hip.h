@@ -124,6 +124,38 @@ int tstar_owl_debug_preprocess(tstar_owl* h, const uint8_t* d_images, int B, int
                                uint8_t* d_out_u8 /* [B,768,768,3] */, float* d_out_patches /* [B*576,3072] */,
                                void* stream);
 
+/* ------------------------------------------------------------------ second detector backend: YOLO-World (D13)
+ * Replaces YoloWorldInterface (interface_heuristic.py:39-190; wired at TStarFramework.py:178-184) -- the mmdet test
+ * pipeline (keep-ratio resize to 640, letterbox pad 114, /255, channel swap), model.test_step (YOLOv8 CSPDarknet,
+ * text-guided PAFPN, BN-contrastive head, DFL decode, class-aware NMS) and the wrapper's `score > 0.12`, top-50
+ * (:148-152) -- with f32 VALU kernels (no MFMA, BASELINE configs[3]).  The model source is NOT in the reference tree
+ * (dangling symlink): the architecture is restated from the published design, parity against the real model is
+ * UNPINNED; oracle/yolo_ref.py is the independent CPU statement the tests compare against.
+ *
+ * The network is handed over as data (tstar_amd/yolo_world.py build_program): a float32 blob (BatchNorm folded), a
+ * table of ops [n_ops][24] int32 over NHWC buffers [n_bufs][3] = (H, W, C), the max-sigmoid attention layers
+ * [n_guides][5] = (embed, heads, guide_fc weight / bias offsets, per-head bias offset) and the head levels
+ * [n_levels][8] = (embedding buffer, DFL buffer, map size, stride, offset of (exp(logit_scale), bias), 0, 0, 0). */
+typedef struct tstar_yolo tstar_yolo;
+int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, const int32_t* h_ops, int n_ops, int op_words,
+                      const int32_t* h_bufs, int n_bufs, const int32_t* h_guides, int n_guides, const int32_t* h_levels,
+                      int n_levels, int input_buf, int max_batch);
+int tstar_yolo_destroy(tstar_yolo* h);
+int tstar_yolo_num_anchors(tstar_yolo* h);
+/* model.reparameterize(texts) (interface_heuristic.py:93): the cached CLIP text features float32 [Q,512] of query set
+ * `query_set` (as the text backbone returns them: L2-normalised) + the searcher's class weights float64 [Q].  Synchronises. */
+int tstar_yolo_set_text_feats(tstar_yolo* h, int query_set, const float* h_text, const double* h_class_weight, int Q, void* stream);
+int tstar_yolo_set_class_weights(tstar_yolo* h, int query_set, const double* h_class_weight, int Q, void* stream);
+/* inference_detector (:136-168) for B equally sized images u8 [B,H,W,3] (+ the searcher's detection -> cell loop,
+ * interface_searcher.py:129-150, when d_cell_conf is given):
+ *   d_det_scores f32 [B,max_dets], d_det_labels i32 [B,max_dets] (-1 = empty), d_det_boxes f32 [B,max_dets,4] xyxy pixels of
+ *   the passed image, descending score; d_n_det i32 [B]; d_cell_conf f64 / d_cell_mask u32 [B,rows*cols] (may both be NULL);
+ *   d_dense_scores f32 [B,8400,Q] / d_dense_boxes f32 [B,8400,4] (diagnostics, may be NULL). */
+int tstar_yolo_detect(tstar_yolo* h, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
+                      const int32_t* h_image_query_set, float score_threshold, int max_dets, float* d_det_scores,
+                      int32_t* d_det_labels, float* d_det_boxes, int32_t* d_n_det, double* d_cell_conf, uint32_t* d_cell_mask,
+                      float* d_dense_scores, float* d_dense_boxes, void* stream);
+
 /* ------------------------------------------------------------------ ingest (S1-S3, S8) */
 /* The resident decoded video d_video is u8 [N,H,W,3] RGB (nv12 = 0) or NV12 u8 [N, H*3/2, W] (nv12 = 1:
  * luma plane + interleaved half-resolution UV plane, converted on the fly, BT.601 limited range, nearest

@@ -33,6 +33,12 @@ SIGNATURES = {
     "tstar_owl_get_query_embeds": (_i, [_vp, _i, _vp, _i, _vp]),
     "tstar_owl_score": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tstar_owl_debug_preprocess": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "tstar_yolo_create": (_i, [C.POINTER(_vp), _vp, _sz, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i]),
+    "tstar_yolo_destroy": (_i, [_vp]),
+    "tstar_yolo_num_anchors": (_i, [_vp]),
+    "tstar_yolo_set_text_feats": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "tstar_yolo_set_class_weights": (_i, [_vp, _i, _vp, _i, _vp]),
+    "tstar_yolo_detect": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tstar_frames_to_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "tstar_frames_resize": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
     "tstar_nv12_to_rgb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),

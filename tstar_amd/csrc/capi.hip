@@ -82,7 +82,7 @@ struct tstar_owl {
     float* d_text = nullptr;
     VisionW vw{};
     TextW tw{};
-    bool has_text = false;
+    bool has_text = false, has_vision = false;
     float* d_lut = nullptr;
     int max_batch = 0;
     size_t mpad = 0;
@@ -252,7 +252,9 @@ static int make_bf16_copies(tstar_owl* h, int mode) {
 
 int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision, const float* h_text_blob,
                      size_t n_text, const float* h_norm_lut, int max_batch, int weights_mode) {
-    TSTAR_REQUIRE(out && h_vision_blob && h_norm_lut, "tstar_owl_create: null argument");
+    TSTAR_REQUIRE(out && (h_vision_blob || h_text_blob), "tstar_owl_create: null argument");
+    TSTAR_REQUIRE(!h_vision_blob || h_norm_lut, "tstar_owl_create: the vision tower needs the normalisation LUT");
+    TSTAR_REQUIRE(h_vision_blob || weights_mode == TSTAR_WEIGHTS_F32, "tstar_owl_create: a text-only handle runs in float32");
     TSTAR_REQUIRE(max_batch >= 1 && max_batch <= 1024, "tstar_owl_create: max_batch must be in 1..1024");
     TSTAR_REQUIRE(weights_mode >= TSTAR_WEIGHTS_F32 && weights_mode <= TSTAR_WEIGHTS_F32_SPLIT,
                   "tstar_owl_create: weights_mode must be 0 (f32), 1 (bf16) or 2 (f32 split)");
@@ -262,9 +264,12 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
         return TSTAR_ERR_HIP;
     }
     tstar_owl* h = new tstar_owl();
-    int rc = upload_blob(h_vision_blob, n_vision, &h->d_vision,
-                         [&](auto&& take) { map_vision(h->vw, take); });
-    if (rc) { delete h; return rc; }
+    int rc = TSTAR_OK;
+    if (h_vision_blob) {               // NULL: a text-only handle (CLIP text features for the YOLO-World backend)
+        rc = upload_blob(h_vision_blob, n_vision, &h->d_vision, [&](auto&& take) { map_vision(h->vw, take); });
+        if (rc) { delete h; return rc; }
+        h->has_vision = true;
+    }
     if (h_text_blob) {
         rc = upload_blob(h_text_blob, n_text, &h->d_text, [&](auto&& take) { map_text(h->tw, take); });
         if (rc) { tstar_owl_destroy(h); return rc; }
@@ -289,7 +294,7 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
     if (e == hipSuccess) e = hipMalloc(&h->d_ids, TSTAR_OWL_MAX_QUERIES * T_LEN * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->d_eos, TSTAR_OWL_MAX_QUERIES * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->d_kmask, TSTAR_OWL_MAX_QUERIES * T_LEN);
-    if (e == hipSuccess) e = hipMemcpy(h->d_lut, h_norm_lut, 768 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && h_norm_lut) e = hipMemcpy(h->d_lut, h_norm_lut, 768 * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         set_error(std::string("tstar_owl_create: workspace allocation failed: ") + hipGetErrorString(e));
         tstar_owl_destroy(h);
@@ -407,6 +412,7 @@ int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, 
                   "tstar_owl_score: null argument");
     TSTAR_REQUIRE(B >= 1 && H >= 1 && W >= 1, "tstar_owl_score: empty batch or image");
     TSTAR_REQUIRE(grid_rows >= 1 && grid_cols >= 1, "tstar_owl_score: grid must be at least 1x1");
+    if (!h->has_vision) { set_error("tstar_owl_score: handle was created without vision weights (text-only)"); return TSTAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
     int q_uniform = -1;                                   // the common Q when every image uses one set size
     for (int b = 0; b < B; ++b) {
@@ -469,6 +475,7 @@ int tstar_owl_debug_preprocess(tstar_owl* h, const uint8_t* d_images, int B, int
                                float* d_out_patches, void* stream) {
     TSTAR_REQUIRE(h && d_images && d_out_patches, "tstar_owl_debug_preprocess: null argument");
     TSTAR_REQUIRE(B >= 1 && B <= h->max_batch, "tstar_owl_debug_preprocess: B must be in 1..max_batch");
+    if (!h->has_vision) { set_error("tstar_owl_debug_preprocess: handle was created without vision weights (text-only)"); return TSTAR_ERR_STATE; }
     return preprocess_chunk(h, d_images, B, H, W, d_out_u8, d_out_patches, (hipStream_t)stream);
 }
 

@@ -15,16 +15,21 @@ Same names, argument meaning and behaviour as the reference where a caller can o
 
 Documented deviations: no ``./annotated_image.png`` is written per call (the reference's debug
 block, :248-255, costs ~50 ms per call); the text tower runs once per
-``reparameterize_object_list`` instead of once per detector call (it is constant per question);
-``YoloWorldInterface`` is not provided (its source is absent from the reference checkout --
-SURVEY.md 8c -- and it needs mmdet; requesting it raises NotImplementedError like an unknown
-heuristic type does in TStarFramework.initialize_heuristic, TStarFramework.py:187).
+``reparameterize_object_list`` instead of once per detector call (it is constant per question).
+
+``YoloWorldInterface`` (:39-190) is the second backend: the reference reaches YOLO-World through mmdet /
+mmyolo and a repository that is NOT part of its tree, so the detector here is a from-scratch HIP
+implementation of the published YOLO-World-v2 architecture (f32 VALU kernels, no MFMA -- BASELINE
+configs[3]) whose parity against the real model is unpinned (oracle/yolo_ref.py states why); the
+WRAPPER semantics the reference itself defines are kept: ``texts`` layout with the trailing blank
+query, ``score > 0.12`` then top-50, only ``images[0]``, ``detections_inbatch``.
 
 Extensions used by tstar_amd.TStarSearcher's batched fast path (a foreign heuristic without them
 still works through ``inference_detector``): ``set_class_weights``, ``score_batch``.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -201,6 +206,160 @@ class OWLInterface(HeuristicInterface):
                           class_id=r.labels[b].cpu().numpy()[keep].astype(np.int64))
 
 
+def _yolo_scale_from_config(config_path: Optional[str]) -> str:
+    """'yolo_world_v2_xl_vlpan_...' -> 'x' (the reference wires the XL config, TStarFramework.py:181); BASELINE configs[3]
+    names the L model, which is the default when the name says nothing."""
+    import re
+    m = re.search(r"yolo_world(?:_v2)?_(s|m|l|xl|x)_", os.path.basename(str(config_path or "")))
+    return {"xl": "x"}.get(m.group(1), m.group(1)) if m else "l"
+
+
+class YoloWorldInterface(HeuristicInterface):
+    def __init__(self, config_path: Optional[str] = None, checkpoint_path: Optional[str] = None, device: str = "cuda:0", *,
+                 scale: Optional[str] = None, synthetic_seed: Optional[int] = None, state_dict: Optional[Dict] = None,
+                 text_state_dict: Optional[Dict] = None, max_batch: int = 16):
+        """Arguments as the reference (:40-47: ``config_path``, ``checkpoint_path``, ``device``).  The mmengine config is
+        only consulted for the model scale (its file name); weights come from ``state_dict`` (mmyolo / YOLO-World names),
+        else ``checkpoint_path`` if that file exists (a torch checkpoint with a ``state_dict`` entry), else -- only when
+        ``synthetic_seed`` is not None -- seeded synthetic parameters (there is no network to fetch a checkpoint).
+        The CLIP text tower (HuggingCLIPLanguageBackbone in the real model) is the HIP text tower shared with the
+        OWL-ViT backend, fed from ``text_state_dict`` (HF OWL-ViT / CLIP text names) or the checkpoint's
+        ``backbone.text_model`` entries or synthetic weights."""
+        import torch
+        from .owl import OwlScorer
+        from .yolo import YoloDetector
+        from . import yolo_world as YW
+        if not str(device).startswith("cuda"):
+            raise ValueError("tstar_amd.YoloWorldInterface runs on the GPU only (device='cuda[:i]'); it has no CPU path")
+        dev = torch.device(device)
+        if dev.index is not None:
+            torch.cuda.set_device(dev.index)
+        self.config_path, self.checkpoint_path, self.device = config_path, checkpoint_path, device
+        self.scale = scale or _yolo_scale_from_config(config_path)
+        if state_dict is None and checkpoint_path and os.path.isfile(checkpoint_path):
+            ck = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+            ck = ck.get("state_dict", ck)
+            state_dict = {k: v.float().numpy() for k, v in ck.items() if hasattr(v, "numpy")}
+            self.weights_source = checkpoint_path
+        elif state_dict is not None:
+            self.weights_source = "state_dict"
+        elif synthetic_seed is not None:
+            state_dict = YW.synthetic_state_dict(int(synthetic_seed), self.scale)
+            self.weights_source = f"synthetic(seed={int(synthetic_seed)})"
+        else:
+            raise FileNotFoundError(
+                f"no YOLO-World checkpoint at {checkpoint_path!r} (offline); pass synthetic_seed=<int> for seeded synthetic "
+                f"YOLO-World-v2-{self.scale.upper()} weights or state_dict=<mmyolo state dict>")
+        if text_state_dict is None:
+            pre = "backbone.text_model.model."
+            clip = {k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre)}
+            if clip:          # HF CLIPTextModelWithProjection names -> the OWL-ViT text tower's names
+                text_state_dict = {("owlvit." + k) if not k.startswith("text_projection") else "owlvit." + k: np.asarray(v, np.float32)
+                                   for k, v in clip.items()}
+                pos = "owlvit.text_model.embeddings.position_embedding.weight"
+                if pos in text_state_dict:
+                    text_state_dict[pos] = text_state_dict[pos][:W.T_LEN]          # 77 CLIP positions, queries use <= 16
+            elif self.weights_source.startswith("synthetic("):
+                text_state_dict = W.synthetic_state_dict(int(synthetic_seed), "text")
+            else:
+                raise FileNotFoundError("the YOLO-World state dict carries no CLIP text tower; pass text_state_dict=")
+        self.allow_standin_tokenizer = self.weights_source.startswith("synthetic(")
+        self.detector = YoloDetector(state_dict, self.scale, max_batch=max_batch)
+        self.text_tower = OwlScorer(None, W.pack_blob(text_state_dict, W.text_spec()), max_batch=1)
+        self.model_name_or_path = "openai/clip-vit-base-patch32"
+        self.texts = []
+        self.detections_inbatch: List[Detections] = []
+        self._text_feats = None
+        self.set_BBoxAnnotator()
+
+    def set_BBoxAnnotator(self):
+        """(:68-76) the reference builds supervision annotators; boxes are painted by ``draw_boxes`` here."""
+        self.BOUNDING_BOX_ANNOTATOR = draw_boxes
+        self.LABEL_ANNOTATOR = None
+
+    # ---- reference surface -------------------------------------------------------------
+    def _encode(self, texts, weights, slot):
+        ids, am = encode_queries(texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
+        self.text_tower.set_queries(ids, am, weights, slot=0)
+        feats = self.text_tower.get_query_embeds(0)              # text_embeds / ||text_embeds|| (the backbone's forward_text)
+        self.detector.set_text_feats(feats, weights, slot=slot)
+        return feats
+
+    def reparameterize_object_list(self, target_objects: List[str], cue_objects: List[str]):
+        """(:78-93) texts = [[name.strip()], ..., [' ']]; ``model.reparameterize(texts)`` caches the text features."""
+        combined = list(target_objects) + list(cue_objects)
+        self.texts = [[obj.strip()] for obj in combined] + [[' ']]
+        w = [1.0] * len(target_objects) + [0.5] * len(cue_objects) + [0.5]
+        self._text_feats = self._encode(self.texts, w, 0)
+        self._class_weight = np.asarray(w, dtype=np.float64)
+
+    def inference_detector(self, images, max_dets: int = 50, score_threshold: float = 0.12, use_amp: bool = False) -> List[Detections]:
+        """(:136-168) only ``images[0]``; detections with score > ``score_threshold``, the ``max_dets`` best, descending."""
+        import torch
+        img = np.array(images[0], dtype=np.uint8, order="C")
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("inference_detector expects HxWx3 uint8 RGB images")
+        r = self.detector.detect(torch.from_numpy(img).cuda().unsqueeze(0), 1, 1, score_threshold=score_threshold, max_dets=max_dets,
+                                 want_cells=False)
+        dets = [self._detections_from(r, 0)]
+        self.detect_outputs_raw = r
+        self.detections_inbatch = dets
+        return dets
+
+    def inference(self, image, max_dets: int = 100, score_threshold: float = 0.3, use_amp: bool = False) -> Detections:
+        """(:96-134) detector on an image FILE.  mmdet's LoadImageFromFile hands BGR to the pipeline, whose preprocessor
+        swaps to RGB; ``inference_detector`` receives RGB and (as in the reference) lets the same swap happen, so the file
+        is decoded to BGR order here to end up with the channel order the model was trained on."""
+        from PIL import Image
+        with Image.open(image) as im:
+            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+        return self.inference_detector([np.ascontiguousarray(rgb[:, :, ::-1])], max_dets=max_dets, score_threshold=score_threshold)[0]
+
+    def bbox_visualization(self, images, detections_inbatch):
+        """(:170-190) annotated COPIES; like the reference, every entry annotates ``images[len(detections_inbatch) - 1]``."""
+        out = []
+        for detections in detections_inbatch:
+            image = images[len(detections_inbatch) - 1]
+            out.append(draw_boxes(image.copy(), detections))
+        return out
+
+    # ---- fast-path extensions (same contract as OWLInterface) -----------------------------
+    def set_class_weights(self, object2weight: Dict[str, float]):
+        w = [float(object2weight.get(t[0], 0.5)) for t in self.texts]
+        self.detector.set_class_weights(w)
+        self._class_weight = np.asarray(w, dtype=np.float64)
+
+    def score_batch(self, d_images, grid_rows: int, grid_cols: int, image_sets=None):
+        return self.detector.detect(d_images, grid_rows, grid_cols, score_threshold=0.12, max_dets=50, image_sets=image_sets)
+
+    def install_queries(self, slot: int, target_objects: List[str], cue_objects: List[str],
+                        object2weight: Optional[Dict[str, float]] = None) -> List[List[str]]:
+        if not 1 <= int(slot) <= 31:
+            raise ValueError("install_queries: slot must be in 1..31")
+        texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
+        o2w = dict(object2weight or {})
+        for o in target_objects:
+            o2w.setdefault(o, 1.0)
+        for o in cue_objects:
+            o2w.setdefault(o, 0.5)
+        self._encode(texts, [float(o2w.get(t[0], 0.5)) for t in texts], int(slot))
+        return texts
+
+    def annotated_batch(self, d_images, r, start: int = 0, count: Optional[int] = None):
+        """Images + detections of a ``score_batch`` result on the host, boxes painted (<= 50 per image: host painter)."""
+        count = int(d_images.shape[0]) if count is None else int(count)
+        imgs = d_images.cpu().numpy()
+        dets = [self._detections_from(r, start + k) for k in range(count)]
+        for k in range(count):
+            draw_boxes(imgs[k], dets[k])
+        return imgs, dets
+
+    def _detections_from(self, r, b: int) -> Detections:
+        n = int(r.n_kept[b].item())
+        return Detections(xyxy=r.boxes[b, :n].cpu().numpy(), confidence=r.scores[b, :n].cpu().numpy(),
+                          class_id=r.labels[b, :n].cpu().numpy().astype(np.int64))
+
+
 def draw_boxes(image: np.ndarray, det: Detections, color=(255, 64, 64)) -> np.ndarray:
     """1-px rectangles painted IN PLACE on ``image`` (the reference's supervision BoxAnnotator also
     paints on the array it is given, Appendix B.14) and returned."""
@@ -224,9 +383,10 @@ def initialize_heuristic(heuristic_type: str = "owl-vit", **kwargs) -> Heuristic
     if heuristic_type == "owl-vit":
         return OWLInterface(model_name_or_path="google/owlvit-base-patch32", **kwargs)
     if heuristic_type == "yolo-World":
-        # the reference wires YOLO-World through mmdet/mmyolo and a repository cloned at install time
-        # (TStarFramework.py:178-184, install.sh); none of that source is in the reference tree, so there is
-        # nothing to pin a HIP implementation against
-        raise NotImplementedError("Heuristic type 'yolo-World' is not built in tstar_amd (its detector source is "
-                                  "not part of the reference tree); use 'owl-vit'.")
+        # the paths the reference hard-codes (TStarFramework.py:181-182); the checkpoint is used when it exists
+        config_path = "./YOLO-World/configs/pretrain/yolo_world_v2_xl_vlpan_bn_2e-3_100e_4x8gpus_obj365v1_goldg_train_lvis_minival.py"
+        checkpoint_path = "./pretrained/YOLO-World/yolo_world_v2_xl_obj365v1_goldg_cc3mlite_pretrain-5daf1395.pth"
+        kwargs.setdefault("config_path", config_path)
+        kwargs.setdefault("checkpoint_path", checkpoint_path)
+        return YoloWorldInterface(**kwargs)
     raise NotImplementedError(f"Heuristic type '{heuristic_type}' is not implemented.")

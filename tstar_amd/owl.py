@@ -53,8 +53,10 @@ class OwlScorer:
 
     WEIGHTS_MODES = {"f32": 0, "bf16": 1, "f32_split": 2}      # TSTAR_WEIGHTS_* of include/tstar_hip.h
 
-    def __init__(self, vision_blob: np.ndarray, text_blob: Optional[np.ndarray] = None, max_batch: int = 32,
+    def __init__(self, vision_blob: Optional[np.ndarray], text_blob: Optional[np.ndarray] = None, max_batch: int = 32,
                  weights_mode: str = "f32"):
+        """``vision_blob=None`` gives a text-only handle: ``set_queries`` / ``get_query_embeds`` work (the CLIP text
+        features of the YOLO-World backend), ``score`` raises."""
         import torch
         if not torch.cuda.is_available():
             raise _lib.TStarHipError("OwlScorer needs a HIP device (torch.cuda.is_available() is False); "
@@ -63,13 +65,16 @@ class OwlScorer:
             raise ValueError("weights_mode must be one of " + ", ".join(repr(k) for k in self.WEIGHTS_MODES))
         self._torch = torch
         self._lib = _lib.load()
-        vision_blob = np.ascontiguousarray(vision_blob, dtype=np.float32)
+        if vision_blob is None and text_blob is None:
+            raise ValueError("OwlScorer needs vision weights, text weights, or both")
+        if vision_blob is not None:
+            vision_blob = np.ascontiguousarray(vision_blob, dtype=np.float32)
         if text_blob is not None:
             text_blob = np.ascontiguousarray(text_blob, dtype=np.float32)
         lut = normalize_lut()
         h = C.c_void_p()
         rc = self._lib.tstar_owl_create(
-            C.byref(h), vision_blob.ctypes.data, vision_blob.size,
+            C.byref(h), None if vision_blob is None else vision_blob.ctypes.data, 0 if vision_blob is None else vision_blob.size,
             None if text_blob is None else text_blob.ctypes.data, 0 if text_blob is None else text_blob.size,
             lut.ctypes.data, int(max_batch), self.WEIGHTS_MODES[weights_mode])
         _lib.check(rc, "tstar_owl_create")

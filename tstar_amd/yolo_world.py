@@ -139,8 +139,8 @@ def synthetic_state_dict(seed: int = 0, scale: str = "l") -> "OrderedDict[str, n
         sd[c + "norm.bias"] = (0.1 * rs.standard_normal(TEXT_DIM)).astype(np.float32)
         sd[c + "norm.running_mean"] = (0.1 * rs.standard_normal(TEXT_DIM)).astype(np.float32)
         sd[c + "norm.running_var"] = (0.8 + 0.4 * rs.random_sample(TEXT_DIM)).astype(np.float32)
-        sd[c + "bias"] = np.float32(-2.4 + 0.2 * i) * np.ones((), np.float32)
-        sd[c + "logit_scale"] = np.float32(-0.3) * np.ones((), np.float32)
+        sd[c + "bias"] = np.float32(-2.6 + 0.2 * i) * np.ones((), np.float32)
+        sd[c + "logit_scale"] = np.float32(1.6 - 0.4 * i) * np.ones((), np.float32)
     return sd
 
 
