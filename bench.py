@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--lockstep", type=int, default=4,
                     help="independent (video, question) items advanced in lock-step per detector batch "
                          "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time")
+    ap.add_argument("--heuristic", choices=["owl", "yolo"], default="owl",
+                    help="detector backend: owl = OWL-ViT-B/32 (configs[1], the headline); yolo = YOLO-World-v2-L on the f32 VALU, no "
+                         "MFMA (BASELINE configs[3]; parity of that model is unpinned: its source is not in the reference tree)")
     ap.add_argument("--workload", choices=["auto", "single", "haystack", "haystack32"], default="auto",
                     help="single = BASELINE configs[1]: every step searches the SAME resident video with its own sampler seed; "
                          "haystack = configs[2] shape: every step is its own (video, question) item -- a distinct procedural "
@@ -218,6 +221,66 @@ def cpu_baseline(args, stats):
     }
 
 
+def cpu_baseline_yolo(args, stats):
+    """CPU statement of the YOLO-World backend (oracle/yolo_ref.py, torch on the host cores; kind "port": the real model's
+    source is not in the reference tree) timed per detector call the way the reference makes them -- one image per call,
+    letterbox + forward + NMS + the cell loop -- on one grid image and a few verification frames, extrapolated to the GPU
+    run's call mix.  The frame -> grid / 600x285 resizes (cv2 in the reference) are prepared untimed."""
+    import torch
+    from oracle import resize_ref, searcher_ref, yolo_ref
+    from tstar_amd import yolo_world as YW
+    from tstar_amd.video import synthetic_frames_numpy
+    g = args.grid
+    n = g * g
+    sd = YW.synthetic_state_dict(0, "l")
+    rs = np.random.RandomState(0)
+    txt = rs.standard_normal((len(TARGETS) + len(CUES) + 1, 512)).astype(np.float32)
+    txt /= np.linalg.norm(txt, axis=1, keepdims=True)
+    texts = [[o] for o in TARGETS + CUES] + [[" "]]
+    o2w = {**{t: 1.0 for t in TARGETS}, **{c: 0.5 for c in CUES}}
+    secs = list(np.arange(0, args.nframes, args.nframes // n)[:n])
+    frames = synthetic_frames_numpy(secs, args.nframes, FRAME_H, FRAME_W, seed=0)
+    grid_img = resize_ref.frames_to_grid(list(frames), g, g)
+    nver = min(n, 32)
+    ver_imgs = [resize_ref.cv_bilinear_resize(frames[i], 600, 285) for i in range(nver)]
+
+    def call(img, rows, cols):
+        r = yolo_ref.detect(sd, [img], txt)[0]
+        return searcher_ref.image_grid_score(r["xyxy"], r["labels"], r["scores"], texts, o2w, img.shape[0], img.shape[1], rows, cols)
+
+    call(ver_imgs[0], 1, 1)
+    nt_all = torch.get_num_threads()
+    best_nt, best_t = nt_all, None
+    for nt in sorted({min(c, nt_all) for c in (8, 16, 32, 64, nt_all)}):
+        torch.set_num_threads(nt)
+        call(ver_imgs[0], 1, 1)
+        t0 = time.perf_counter()
+        call(ver_imgs[1 % nver], 1, 1)
+        t_ = time.perf_counter() - t0
+        if best_t is None or t_ < best_t:
+            best_nt, best_t = nt, t_
+    torch.set_num_threads(best_nt)
+    t0 = time.perf_counter()
+    call(grid_img, g, g)
+    t_grid = time.perf_counter() - t0
+    nv, t_ver = 0, 0.0
+    deadline = time.perf_counter() + max(1.0, args.cpu_seconds - t_grid)
+    while nv < nver and time.perf_counter() < deadline:
+        t0 = time.perf_counter()
+        call(ver_imgs[nv], 1, 1)
+        t_ver += time.perf_counter() - t0
+        nv += 1
+    t_ver /= max(nv, 1)
+    per_video = stats["grid_calls"] * t_grid + stats["verify_calls"] * t_ver
+    frames_scored = stats["grid_calls"] * n + stats["verify_calls"]
+    return {"value": frames_scored / per_video, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 grid call ({n} frames, {t_grid:.3f} s) + {nv} verification calls ({t_ver:.3f} s each) of the same workload through "
+                      f"the CPU statement of YOLO-World-v2-L (torch conv2d on the host cores; letterbox incl. a numpy area resize, forward, "
+                      f"NMS, cell loop), extrapolated to the GPU run's call mix ({stats['grid_calls']} grid + {stats['verify_calls']} "
+                      f"verification calls per video); {best_nt} torch threads (fastest of 8/16/32/64/{nt_all}); cv2.resize steps untimed",
+            "sec_per_video": per_video}
+
+
 def main():
     args = parse()
     # the searcher prints progress like the reference ("Found target ...", sampler warnings): keep stdout
@@ -258,8 +321,13 @@ def main():
     import queue
     import threading
     conc = max(1, min(args.concurrency, args.steps))
-    heuristics = [OWLInterface(synthetic_seed=0, max_batch=args.max_batch, device=f"cuda:{local_rank}",
-                               weights_dtype=args.weights) for _ in range(conc)]
+    if args.heuristic == "yolo":
+        from tstar_amd.interface_heuristic import YoloWorldInterface
+        heuristics = [YoloWorldInterface(synthetic_seed=0, scale="l", max_batch=min(args.max_batch, 32), device=f"cuda:{local_rank}")
+                      for _ in range(conc)]
+    else:
+        heuristics = [OWLInterface(synthetic_seed=0, max_batch=args.max_batch, device=f"cuda:{local_rank}",
+                                   weights_dtype=args.weights) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
     g = args.grid
     workload = args.workload
@@ -371,6 +439,8 @@ def main():
     # roofline of the dominant kernel (gemm_f32_kernel): HIP events on the launch stream, this rank
     n_l, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
     _lib.check(lib.tstar_prof_read(0, C.byref(n_l), C.byref(ms), C.byref(fl)))
+    if args.heuristic == "yolo":                  # dominant kernel of the YOLO-World backend: conv_valu_kernel (category 2)
+        _lib.check(lib.tstar_prof_read(2, C.byref(n_l), C.byref(ms), C.byref(fl)))
     a_l, a_ms, a_fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
     _lib.check(lib.tstar_prof_read(1, C.byref(a_l), C.byref(a_ms), C.byref(a_fl)))
     _lib.check(lib.tstar_prof_enable(0))
@@ -389,7 +459,11 @@ def main():
 
     # f32 weights: native f32 MFMA, algorithmic = executed flops.  bf16 weights: each algorithmic product is
     # three bf16 MFMA products (exact activation split), priced against the dense bf16 peak.
-    if args.weights in ("bf16", "f32_split"):
+    bound = "mfma"
+    if args.heuristic == "yolo":
+        gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel (implicit-GEMM convolution, v_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
+        traffic, traffic_src = None, None
+    elif args.weights in ("bf16", "f32_split"):
         gemm_kernel, peak, exec_mult = f"gemm_f32_kernel<WMODE={1 if args.weights == 'bf16' else 2}> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
     else:
         gemm_kernel, peak, exec_mult = "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1.0
@@ -399,8 +473,12 @@ def main():
         verified, verify_detail = verify_keyframes(heuristics[0], items[0], g, args.search_nframes, keys[0])
     wl_name = {"single": "configs[1]", "haystack": "configs[2] shape (weak scaling: --steps items per rank)",
                "haystack32": "configs[2]"}[workload]
+    if args.heuristic == "yolo":
+        wl_name = "configs[3]" if workload == "single" else wl_name + " with the configs[3] backend"
     if args.weights != "f32" or args.nframes != N_FRAMES:
         wl_name = "variant of " + wl_name
+    det_name = ("YOLO-World-v2-L (seeded synthetic weights, f32 VALU kernels, no MFMA; score > 0.12, top-50)" if args.heuristic == "yolo"
+                else f"OWL-ViT-B/32 {args.weights} weights (seeded synthetic)")
     if workload == "single":
         wl_what = (f"ONE {args.nframes}-frame {FRAME_H}x{FRAME_W} synthetic RGB video resident in HBM, 1 question (targets {TARGETS}, "
                    f"cues {CUES}), every step = one full search of it with its own sampler seed")
@@ -420,7 +498,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "collective_backend": (backend if world > 1 else None),
-                "workload": f"{wl_name}: {wl_what}; OWL-ViT-B/32 {args.weights} weights (seeded synthetic), grid {g}x{g} = "
+                "workload": f"{wl_name}: {wl_what}; {det_name}, grid {g}x{g} = "
                             f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
                 "workload_kind": workload, "items_total": n_items_total,
                 "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc, "lockstep_items_per_batch": max(1, min(args.lockstep, 31)),
@@ -431,7 +509,7 @@ def main():
                 "keyframes_verified": verified, "keyframes_verification": verify_detail,
             },
             "roofline": {
-                "kernel": gemm_kernel, "bound": "mfma", "achieved": achieved * exec_mult,
+                "kernel": gemm_kernel, "bound": bound, "achieved": achieved * exec_mult,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved * exec_mult / peak, "traffic": traffic,
                 "achieved_algorithmic": achieved,
                 "traffic_unit": "bytes per launch (L2 fabric side: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
@@ -443,9 +521,12 @@ def main():
                                          "launches_timed": a_l.value, "time_share_of_step": a_ms.value * PROF_STRIDE * 1e-3 / dt / max(conc, 1)},
             },
         }
+        if args.heuristic == "yolo":
+            out["roofline"].pop("attention_f32_kernel", None)
+            out["roofline"]["peak_note"] = "f32 VALU spec peak (v_pk_fma_f32 rate); a tiled f32 VALU GEMM sustains about a third of it on this part (MI355X guide: 52 TFLOP/s)"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, {"grid_calls": grid_calls / args.steps,
-                                                      "verify_calls": verify_calls / args.steps})
+            stats_ = {"grid_calls": grid_calls / args.steps, "verify_calls": verify_calls / args.steps}
+            out["cpu_baseline"] = cpu_baseline_yolo(args, stats_) if args.heuristic == "yolo" else cpu_baseline(args, stats_)
             out["config"]["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:

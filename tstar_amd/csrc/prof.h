@@ -3,7 +3,7 @@
 #include "common.h"
 
 namespace tstar {
-enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_NCAT = 2 };
+enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_CONV = 2, PROF_NCAT = 3 };   // PROF_CONV: conv_valu_kernel (YOLO-World backend)
 bool prof_enabled();
 // record the start / stop events around one launch; `work` = algorithmic flops of the launch
 void prof_start(int cat, hipStream_t s, double work);

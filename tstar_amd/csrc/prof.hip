@@ -12,12 +12,12 @@ struct Cat { std::vector<Pair> pending; std::vector<Pair> pool; long launches = 
 static Cat g_cat[PROF_NCAT];
 static bool g_on = false;
 static int g_stride = 1;            // time every g_stride-th launch of a category
-static long g_seen[PROF_NCAT] = {0, 0};
+static long g_seen[PROF_NCAT] = {0, 0, 0};
 static std::mutex g_mu;      // searches may run on several host threads / streams
 
 bool prof_enabled() { return g_on; }
 
-static thread_local hipEvent_t t_last_b[PROF_NCAT] = {nullptr, nullptr};
+static thread_local hipEvent_t t_last_b[PROF_NCAT] = {nullptr, nullptr, nullptr};
 
 static void drain(Cat& c) {
     for (Pair& p : c.pending) {

@@ -21,6 +21,7 @@
 #include "../../include/tstar_hip.h"
 #include "common.h"
 #include "heads.h"
+#include "prof.h"
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -207,8 +208,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const bool tiled = a.cin % CBK == 0 && a.src_ld % 4 == 0 && a.src_off % 4 == 0 && (a.ks == 1 || a.ks == 3);
     if (tiled) {
         const dim3 grid(cdiv(a.M, CBM), cdiv(a.cout, CBN));
+        const bool prof = prof_enabled();
+        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
         if (a.ks == 1) hipLaunchKernelGGL(conv_valu_kernel<1>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_valu_kernel<3>, grid, dim3(256), 0, s, a);
+        if (prof) prof_stop(PROF_CONV, s);
     } else {
         TSTAR_REQUIRE(a.mode == MODE_PLAIN, "yolo conv: the direct form has no fused residual / gate");
         const size_t total = (size_t)a.M * (a.cout / 4);
