@@ -19,8 +19,14 @@
 //  * T = 32 n + 1 (577 = 576 patches + CLS): the straggler key is folded in after
 //    the block loop with VALU ops (tail_key) instead of a 19th, 97 % empty block.
 //  * K/V tiles (32 keys) are staged global -> VGPR -> LDS, double-buffered, one
-//    barrier per tile; K rows padded to 68 floats (conflict-free ds_read_b128),
+//    barrier per tile; K rows are 64 floats with an XOR swizzle of the float4
+//    column (conflict-free ds_read_b128, 32 KB of LDS per workgroup),
 //    V read as ds_read_b32 rows (two 32-lane halves never conflict).
+//  * measured and NOT adopted (round 2, tools/bench_attention.py, B = 256): 3- / 6-wave
+//    workgroups that tile the 576 patch queries exactly (92 / 67 TFLOP/s vs 118 for 4 waves:
+//    more K/V staging per MFMA, no SIMD imbalance to win back -- a workgroup's waves land on
+//    the SIMDs cyclically from a varying start); the straggler query 576 in its own VALU-only
+//    workgroup (-15 %: it re-reads all K/V of its head, 20 % more L2 traffic).
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -28,13 +34,17 @@
 
 namespace tstar {
 
-constexpr int HD = 64, KB = 32, K_LD = HD + 4;
+constexpr int HD = 64, KB = 32;
+// K tile rows are 64 floats (one 256-B LDS bank row), un-padded; float4 column j of key row k is stored at column
+// j ^ (k & 15).  ds_read_b128 is serviced in 16-lane groups over 64 banks (MI355X guide, LDS): the 16 lanes of a group
+// must hit 16 distinct 16-B slots, and the S^T fragment read (16 keys with distinct k & 15, one logical column) does.
+__device__ __forceinline__ int kswz(int key, int j) { return (j ^ (key & 15)) * 4; }
 
 template <int MODE>
 __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int T, int heads, int qtiles,
                                                             const uint8_t* __restrict__ key_mask) {
-    __shared__ __attribute__((aligned(16))) float Ks[2][KB][K_LD];
+    __shared__ __attribute__((aligned(16))) float Ks[2][KB][HD];
     __shared__ __attribute__((aligned(16))) float Vs[2][KB][HD];
 
     const int D = heads * HD, D3 = 3 * D;
@@ -45,6 +55,7 @@ __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __re
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
+    const int kx4 = 4 * (h ^ (l31 & 15));
     const size_t rowbase = (size_t)b * T;
 
     // ---- Q fragment (B operand): lane holds Q[q][8c + 4h .. +3], c = 0..7, scaled by log2e/8
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __re
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<f32x4*>(&Ks[0][sr + 16 * i][f4 * 4]) = rk[i];
+        *reinterpret_cast<f32x4*>(&Ks[0][sr + 16 * i][kswz(sr + 16 * i, f4)]) = rk[i];
         *reinterpret_cast<f32x4*>(&Vs[0][sr + 16 * i][f4 * 4]) = rv[i];
     }
     __syncthreads();
@@ -107,11 +118,12 @@ __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __re
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            const float* kp = &Ks[cur][l31][4 * h];
+            const float* kp = &Ks[cur][l31][0];
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                f32x4 ka = *reinterpret_cast<const f32x4*>(kp + 8 * c);
+                // kswz(l31, 2c + h) = (8c) ^ (4 (h ^ (l31 & 15))): one XOR with a per-lane constant
+                f32x4 ka = *reinterpret_cast<const f32x4*>(kp + ((8 * c) ^ kx4));
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[c][e], s, 0, 0, 0);
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __re
         if (more) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                *reinterpret_cast<f32x4*>(&Ks[cur ^ 1][sr + 16 * i][f4 * 4]) = rk[i];
+                *reinterpret_cast<f32x4*>(&Ks[cur ^ 1][sr + 16 * i][kswz(sr + 16 * i, f4)]) = rk[i];
                 *reinterpret_cast<f32x4*>(&Vs[cur ^ 1][sr + 16 * i][f4 * 4]) = rv[i];
             }
         }

@@ -1,7 +1,7 @@
 // fp32 GEMM on the CDNA4 matrix cores: C[M,N] = A[M,K] * W[N,K]^T (+ fused epilogue).
 //
 // This is the dominant kernel of the OWL-ViT scorer (patch-embed, QKV, out-proj,
-// fc1, fc2, head projections: 112.8 of the 114.8 GFLOP per detector image,
+// fc1, fc2, head projections: 102.5 of the 114.8 GFLOP per detector image (attention is the other 12.3),
 // SURVEY.md 8d).  It replaces the torch.nn.Linear / Conv2d calls HF makes in
 // modeling_owlvit.py:336-337, 428-459, 471-475, 993-999, 1020 on behalf of
 // /root/reference/TStar/interface_heuristic.py:237-239.
@@ -450,37 +450,44 @@ static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
     return TSTAR_OK;
 }
 
-// Tile choice, calibrated on MI355X (tools/sweep_hybrid_split.py, tools/bench_gemm_cfg.py).  Blocks are
-// dispatched in index order onto 512 resident slots (256 CUs x 2 blocks; 1024 quarter-size slots for 64x64):
-//  * under a quarter / half of a wave of 128x128 tiles the smaller tiles win simply by putting a block on every CU;
-//  * between half a wave and one wave a smoothed wave model decides (w = blocks / slots, time ~ w + 0.5 beyond
-//    one wave, e_cfg = steady-state rate of the narrower tiles relative to 128x128);
-//  * from one full wave on, the HYBRID launch is never worse than any pure grid and up to 15 % better: as many
-//    whole 512-block waves of 128x128 tiles as fit, the remaining rows as 64x128 tiles, which arrive last and
-//    fill the tail at half the granularity.
+// Tile choice, calibrated on MI355X (tools/sweep_small_m.py for launches under two waves of 128x128 tiles -- the
+// B = 1..16 grid forwards of the reference-default 4x4 grid; tools/sweep_hybrid_split.py, tools/bench_gemm_cfg.py for
+// the batch shapes).  Blocks are dispatched in index order onto 512 resident slots (256 CUs x 2 blocks; 1024
+// quarter-size slots for 64x64).  b128 = number of 128x128 tiles of the problem:
+//  * b128 <= 200: 64x64 tiles (up to 800 quarter-size blocks: every CU gets work; measured best up to there);
+//  * b128 <= 256: 64x128 tiles;
+//  * 256 < b128 < 410: ONE wave of mixed sizes -- the first n row tiles 128 rows high, the rest 64 x 128, with n chosen
+//    so that the launch has about 512 blocks (and at least half of the row tiles big): the small tiles finish first and
+//    leave their CUs to the big ones instead of idling a third of the chip (qkv at B = 4: 76 -> 103 TFLOP/s);
+//  * 410 <= b128 < 512: a pure 128x128 grid (measured best: nearly a full wave);
+//  * 512 <= b128 < 1024: hybrid, half of the row tiles big -- a whole wave of big tiles plus a thin second wave leaves
+//    the chip idle for up to half a tile time (fc1 at B = 5: 91 -> 109 TFLOP/s);
+//  * from two waves on, as many whole 512-block waves of 128x128 tiles as fit, the remaining rows as 64x128 tiles, which
+//    arrive last and fill the tail at half the granularity (never worse than a pure grid, up to +15 %).
 // Returns 0/1/2 for a pure grid, or 3 for the hybrid launch with *m_split set.
 static int pick_cfg(int M, int N, int* m_split) {
     *m_split = 0;
     const int nt = N / 128;
-    const int b128 = cdiv(M, 128) * nt;
-    if (b128 <= 128) return 2;                               // 64x64: up to 512 blocks
-    if (b128 <= 256) return 1;                               // 64x128: up to 512 blocks
-    if (b128 >= 512) {
-        const int big_rows = ((b128 / 512) * 512 / nt) * 128;  // rows covered by whole waves of 128x128 tiles
-        if (big_rows >= M) return 0;
-        *m_split = big_rows;
+    const int mt = cdiv(M, 128);
+    const int b128 = mt * nt;
+    if (b128 <= 200) return 2;                               // 64x64
+    if (b128 <= 256) return 1;                               // 64x128
+    if (b128 < 410 || (b128 >= 512 && b128 < 1024)) {
+        int n_big = mt / 2;
+        if (b128 < 410) {
+            const int fill = 2 * mt - 512 / nt;              // n with nt * (n + 2 (mt - n)) <= 512
+            if (fill > n_big) n_big = fill;
+        }
+        if (n_big > mt - 1) n_big = mt - 1;
+        if (n_big < 1) return 1;
+        *m_split = n_big * 128;
         return 3;
     }
-    auto waves = [](double w) { return w <= 1.0 ? 1.0 : w + 0.5; };
-    const double e64n = 0.96, e64 = 0.93;
-    const double t128 = waves(b128 / 512.0);
-    const double t64n = waves((double)cdiv(M, 64) * nt / 512.0) * 0.5 / e64n;
-    const double t64 = waves((double)cdiv(M, 64) * (N / 64) / 1024.0) * 0.5 / e64;   // 1024 quarter-size slots
-    int best = 0;
-    double tb = t128;
-    if (t64n < tb) { tb = t64n; best = 1; }
-    if (t64 < tb) { tb = t64; best = 2; }
-    return best;
+    if (b128 < 512) return 0;                                // 128x128
+    const int big_rows = ((b128 / 512) * 512 / nt) * 128;    // rows covered by whole waves of 128x128 tiles
+    if (big_rows >= M) return 0;
+    *m_split = big_rows;
+    return 3;
 }
 
 template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
