@@ -19,7 +19,13 @@ numpy restatement of the byte arithmetic in front of the detector:
   /root/reference/TStar/interface_searcher.py:186,362,403.  PARITY UNPINNED:
   cv2 (pin opencv-python 4.10.0, requirements.txt:88) is not importable here and
   the reference has no test for it; this function DEFINES the build's bilinear
-  (it is also what the cv2 stub uses when goldens are generated).
+  (it is also what the cv2 stub uses when goldens are generated).  Known OpenCV
+  behaviour it does not special-case (from upstream knowledge): ``cv::resize``
+  turns INTER_LINEAR into the INTER_AREA fast path when BOTH axes decimate by
+  exactly 2 (e.g. a 1600x760 source -> 800x380).  No branch is needed: at scale 2
+  the linear taps are (2d, 2d+1) with weights 1024 / 1024 and the fixed-point
+  formula below collapses to ``(a + b + c + d + 2) >> 2`` -- the area result
+  (tests/test_oracle_owl.py::test_cv_linear_at_2x_equals_area).
 """
 from __future__ import annotations
 

