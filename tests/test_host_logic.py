@@ -43,11 +43,14 @@ def test_no_cpu_fallback_without_gpu():
 
 
 def test_heuristic_factory_names():
-    """initialize_heuristic keeps the reference's type names (TStarFramework.py:171-187): 'owl-vit' is built,
-    'yolo-World' and unknown names raise NotImplementedError like the reference's else branch."""
-    from tstar_amd.interface_heuristic import initialize_heuristic
-    with pytest.raises(NotImplementedError, match="yolo-World"):
+    """initialize_heuristic keeps the reference's type names (TStarFramework.py:171-187): 'owl-vit' and 'yolo-World' are
+    built (the latter needs weights: nothing can be downloaded), unknown names raise NotImplementedError like the
+    reference's else branch."""
+    from tstar_amd.interface_heuristic import _yolo_scale_from_config, initialize_heuristic
+    with pytest.raises(FileNotFoundError, match="no YOLO-World checkpoint"):
         initialize_heuristic("yolo-World")
+    assert _yolo_scale_from_config("./YOLO-World/configs/pretrain/yolo_world_v2_xl_vlpan_bn_2e-3_100e_4x8gpus_obj365v1_goldg_train_lvis_minival.py") == "x"
+    assert _yolo_scale_from_config("yolo_world_v2_l_vlpan_bn.py") == "l" and _yolo_scale_from_config(None) == "l"
     with pytest.raises(NotImplementedError, match="not implemented"):
         initialize_heuristic("frcnn")
 

@@ -231,11 +231,15 @@ class YoloWorldInterface(HeuristicInterface):
         from . import yolo_world as YW
         if not str(device).startswith("cuda"):
             raise ValueError("tstar_amd.YoloWorldInterface runs on the GPU only (device='cuda[:i]'); it has no CPU path")
+        self.config_path, self.checkpoint_path, self.device = config_path, checkpoint_path, device
+        self.scale = scale or _yolo_scale_from_config(config_path)
+        if state_dict is None and synthetic_seed is None and not (checkpoint_path and os.path.isfile(checkpoint_path)):
+            raise FileNotFoundError(
+                f"no YOLO-World checkpoint at {checkpoint_path!r} (offline); pass synthetic_seed=<int> for seeded synthetic "
+                f"YOLO-World-v2-{self.scale.upper()} weights or state_dict=<mmyolo state dict>")
         dev = torch.device(device)
         if dev.index is not None:
             torch.cuda.set_device(dev.index)
-        self.config_path, self.checkpoint_path, self.device = config_path, checkpoint_path, device
-        self.scale = scale or _yolo_scale_from_config(config_path)
         if state_dict is None and checkpoint_path and os.path.isfile(checkpoint_path):
             ck = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
             ck = ck.get("state_dict", ck)
@@ -243,13 +247,9 @@ class YoloWorldInterface(HeuristicInterface):
             self.weights_source = checkpoint_path
         elif state_dict is not None:
             self.weights_source = "state_dict"
-        elif synthetic_seed is not None:
+        else:
             state_dict = YW.synthetic_state_dict(int(synthetic_seed), self.scale)
             self.weights_source = f"synthetic(seed={int(synthetic_seed)})"
-        else:
-            raise FileNotFoundError(
-                f"no YOLO-World checkpoint at {checkpoint_path!r} (offline); pass synthetic_seed=<int> for seeded synthetic "
-                f"YOLO-World-v2-{self.scale.upper()} weights or state_dict=<mmyolo state dict>")
         if text_state_dict is None:
             pre = "backbone.text_model.model."
             clip = {k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre)}
