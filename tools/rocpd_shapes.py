@@ -10,8 +10,11 @@ def short(name):
 
 c = sqlite3.connect(sys.argv[1])
 agg = {}
-for name, gx, wx, s, e in c.execute("select name, grid_x, workgroup_x, start, end from kernels"):
-    a = agg.setdefault((name, gx // max(wx, 1)), [0, 0])
+for name, gx, gy, wx, wy, s, e in c.execute("select name, grid_x, grid_y, workgroup_x, workgroup_y, start, end from kernels"):
+    nb = gx // max(wx, 1)
+    if gy and gy // max(wy, 1) > 1:
+        nb = f"{nb}x{gy // max(wy, 1)}"
+    a = agg.setdefault((name, nb), [0, 0])
     a[0] += 1
     a[1] += e - s
 tot = sum(v[1] for v in agg.values())

@@ -168,39 +168,73 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a) {
     }
 }
 
-// direct form for the odd shapes (the 3-channel stem): one lane per (pixel, 4 output channels)
+// direct form for small K = ks*ks*cin (the 3-channel stem: K = 27): the whole weight matrix sits in LDS as [K][cout];
+// a lane computes 4 neighbouring pixels x 16 output channels, so every weight quad read from LDS feeds 16 FMAs and the
+// 64-channel output row of a pixel is written as 16-byte stores.  HBM-bound by its output (64 channels x 4 B per pixel).
+constexpr int DPIX = 4, DCH = 16;
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nq = a.cout / 4;
-    if (gid >= (size_t)a.M * nq) return;
-    const int m = (int)(gid / nq), nb = (int)(gid % nq) * 4;
-    const int hw = a.Ho * a.Wo, b = m / hw, rem = m - b * hw;
-    const int oy = rem / a.Wo, ox = rem % a.Wo;
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [K][cout]
     const int K = a.ks * a.ks * a.cin;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int ky = 0; ky < a.ks; ++ky) {
-        const int iy = oy * a.stride - (a.ks >> 1) + ky;
-        if (iy < 0 || iy >= a.H) continue;
-        for (int kx = 0; kx < a.ks; ++kx) {
-            const int ix = ox * a.stride - (a.ks >> 1) + kx;
-            if (ix < 0 || ix >= a.W) continue;
-            const float* s = a.src + ((size_t)(b * a.H + iy) * a.W + ix) * a.src_ld + a.src_off;
-            const float* w = a.w + (size_t)nb * K + (ky * a.ks + kx) * a.cin;
-            for (int c = 0; c < a.cin; ++c) {
-                const float v = s[c];
+    for (int i = threadIdx.x; i < K * a.cout; i += blockDim.x) {
+        const int n = i % a.cout, k = i / a.cout;
+        wl[i] = a.w[(size_t)n * K + k];
+    }
+    __syncthreads();
+    const int ncg = a.cout / DCH;
+    const int pq = threadIdx.x / ncg, cg = threadIdx.x % ncg;
+    const int ppb = (blockDim.x / ncg) * DPIX;                       // pixels per block
+    const int mbase = blockIdx.x * ppb + pq * DPIX;
+    if (pq >= blockDim.x / ncg) return;
+    float acc[DPIX][DCH];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, w[(size_t)j * K + c], acc[j]);
+    for (int i = 0; i < DPIX; ++i)
+#pragma unroll
+        for (int j = 0; j < DCH; ++j) acc[i][j] = 0.f;
+    int pb[DPIX], py[DPIX], px[DPIX];
+    const int hw = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < DPIX; ++i) {
+        const int m = mbase + i < a.M ? mbase + i : a.M - 1;
+        pb[i] = m / hw;
+        const int rem = m - pb[i] * hw;
+        py[i] = (rem / a.Wo) * a.stride - (a.ks >> 1);
+        px[i] = (rem % a.Wo) * a.stride - (a.ks >> 1);
+    }
+    for (int ky = 0; ky < a.ks; ++ky)
+        for (int kx = 0; kx < a.ks; ++kx)
+            for (int c = 0; c < a.cin; ++c) {
+                const float* wr = wl + (size_t)((ky * a.ks + kx) * a.cin + c) * a.cout + cg * DCH;
+                f32x4 w4[DCH / 4];
+#pragma unroll
+                for (int q = 0; q < DCH / 4; ++q) w4[q] = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+#pragma unroll
+                for (int i = 0; i < DPIX; ++i) {
+                    const int iy = py[i] + ky, ix = px[i] + kx;
+                    float v = 0.f;
+                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = a.src[((size_t)(pb[i] * a.H + iy) * a.W + ix) * a.src_ld + a.src_off + c];
+#pragma unroll
+                    for (int q = 0; q < DCH / 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = fmaf(v, w4[q][e], acc[i][4 * q + e]);
+                }
             }
+#pragma unroll
+    for (int i = 0; i < DPIX; ++i) {
+        const int m = mbase + i;
+        if (m >= a.M) continue;
+        float* o = a.dst + (size_t)m * a.dst_ld + a.dst_off + cg * DCH;
+#pragma unroll
+        for (int q = 0; q < DCH / 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[i][4 * q + e] + (a.bias ? a.bias[cg * DCH + 4 * q + e] : 0.f);
+                if (a.act == YACT_SILU) t = silu(t);
+                v[e] = t;
+            }
+            *reinterpret_cast<f32x4*>(o + 4 * q) = v;
         }
     }
-    f32x4 v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float t = acc[j] + (a.bias ? a.bias[nb + j] : 0.f);
-        if (a.act == YACT_SILU) t = silu(t);
-        v[j] = t;
-    }
-    *reinterpret_cast<f32x4*>(a.dst + (size_t)m * a.dst_ld + a.dst_off + nb) = v;
 }
 
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
@@ -215,8 +249,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         if (prof) prof_stop(PROF_CONV, s);
     } else {
         TSTAR_REQUIRE(a.mode == MODE_PLAIN, "yolo conv: the direct form has no fused residual / gate");
-        const size_t total = (size_t)a.M * (a.cout / 4);
-        hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        const int K = a.ks * a.ks * a.cin;
+        TSTAR_REQUIRE(a.cout % DCH == 0 && a.cout / DCH <= 256 && (size_t)K * a.cout * 4 <= 64 * 1024,
+                      "yolo conv: the direct (small-K) form needs cout % 16 == 0 and its weights in 64 KB of LDS");
+        const int ncg = a.cout / DCH, nthreads = (256 / ncg) * ncg, ppb = (nthreads / ncg) * DPIX;
+        hipLaunchKernelGGL(conv_direct_kernel, dim3(cdiv(a.M, ppb)), dim3(nthreads), (size_t)K * a.cout * 4, s, a);
     }
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
@@ -379,58 +416,75 @@ struct DecodeArgs {
     float* dense_scores; int dense_q;                         // optional [B, n_anchor, dense_q]
 };
 
-// one wave per anchor: DFL expectation + decode + un-letterbox; scores against every query of the image's set;
-// (score, anchor, class) pairs above the candidate threshold appended to the image's list
+// 16 anchors of ONE image per workgroup (4 per wave, one after the other): DFL expectation + decode + un-letterbox;
+// scores against every query of the image's set; (score, anchor, class) pairs above the candidate threshold are
+// collected in LDS and appended to the image's list with ONE global atomic per workgroup (every anchor appending on its
+// own serialised ~8 x 10^5 atomics on a few counters: 9 ms of a 100 ms forward)
+constexpr int HD_APB = 16;                                          // anchors per block
 __global__ __launch_bounds__(256) void head_decode_kernel(DecodeArgs a, int rows) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int img = row / a.HW, p = row - img * a.HW;
-    const int anchor = a.anchor0 + p;
-    // DFL: lane = side * 16 + bin
-    const float r = a.R[(size_t)row * 64 + lane];
-    float mx = r;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float e = expf(r - mx);
-    float se = e, sw = e * (float)(lane & 15);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { se += __shfl_xor(se, o); sw += __shfl_xor(sw, o); }
-    const float dist = (sw / se) * (float)a.stride;
-    const float d0 = __shfl(dist, 0), d1 = __shfl(dist, 16), d2 = __shfl(dist, 32), d3 = __shfl(dist, 48);
-    const float px = ((float)(p % a.Wl) + 0.5f) * (float)a.stride, py = ((float)(p / a.Wl) + 0.5f) * (float)a.stride;
-    if (lane == 0) {
-        f32x4 bx;
-        bx[0] = (px - d0 - a.pad_left) / a.sf_w; bx[1] = (py - d1 - a.pad_top) / a.sf_h;
-        bx[2] = (px + d2 - a.pad_left) / a.sf_w; bx[3] = (py + d3 - a.pad_top) / a.sf_h;
-        *reinterpret_cast<f32x4*>(a.boxes + ((size_t)img * a.n_anchor + anchor) * 4) = bx;
-    }
-    // classification: <E[row], textn[k]> * exp(logit_scale) + bias -> sigmoid
+    __shared__ unsigned long long s_cand[HD_APB * YOLO_MAX_Q];
+    __shared__ int s_n, s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int row0 = blockIdx.x * HD_APB;
+    const int img = row0 / a.HW;                                     // HW % 16 == 0: a block never straddles two images
     const int set = a.image_set ? a.image_set[img] : 0;
     const int Q = a.setQ[set];
-    const float* er = a.E + (size_t)row * YOLO_TEXT;
-    float ev[8];
+    for (int ai = 0; ai < HD_APB / 4; ++ai) {
+        const int row = row0 + wave * (HD_APB / 4) + ai;
+        if (row >= rows) break;
+        const int p = row - img * a.HW;
+        const int anchor = a.anchor0 + p;
+        // DFL: lane = side * 16 + bin
+        const float r = a.R[(size_t)row * 64 + lane];
+        float mx = r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ev[i] = er[i * 64 + lane];
-    for (int k = 0; k < Q; ++k) {
-        const float* t = a.textn + ((size_t)set * YOLO_MAX_Q + k) * YOLO_TEXT;
-        float d = 0.f;
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = expf(r - mx);
+        float se = e, sw = e * (float)(lane & 15);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d = fmaf(ev[i], t[i * 64 + lane], d);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        for (int o = 8; o > 0; o >>= 1) { se += __shfl_xor(se, o); sw += __shfl_xor(sw, o); }
+        const float dist = (sw / se) * (float)a.stride;
+        const float d0 = __shfl(dist, 0), d1 = __shfl(dist, 16), d2 = __shfl(dist, 32), d3 = __shfl(dist, 48);
+        const float px = ((float)(p % a.Wl) + 0.5f) * (float)a.stride, py = ((float)(p / a.Wl) + 0.5f) * (float)a.stride;
         if (lane == 0) {
-            const float logit = d * a.logit_scale + a.bias;
-            const float sc = 1.0f / (1.0f + expf(-logit));
-            if (a.dense_scores) a.dense_scores[((size_t)img * a.n_anchor + anchor) * a.dense_q + k] = sc;
-            if (sc > a.cand_thr) {
-                const int slot = atomicAdd(&a.cand_count[img], 1);
-                if (slot < a.cand_cap) {
+            f32x4 bx;
+            bx[0] = (px - d0 - a.pad_left) / a.sf_w; bx[1] = (py - d1 - a.pad_top) / a.sf_h;
+            bx[2] = (px + d2 - a.pad_left) / a.sf_w; bx[3] = (py + d3 - a.pad_top) / a.sf_h;
+            *reinterpret_cast<f32x4*>(a.boxes + ((size_t)img * a.n_anchor + anchor) * 4) = bx;
+        }
+        // classification: <E[row], textn[k]> * exp(logit_scale) + bias -> sigmoid
+        const float* er = a.E + (size_t)row * YOLO_TEXT;
+        float ev[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ev[i] = er[i * 64 + lane];
+        for (int k = 0; k < Q; ++k) {
+            const float* t = a.textn + ((size_t)set * YOLO_MAX_Q + k) * YOLO_TEXT;
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d = fmaf(ev[i], t[i * 64 + lane], d);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            if (lane == 0) {
+                const float logit = d * a.logit_scale + a.bias;
+                const float sc = 1.0f / (1.0f + expf(-logit));
+                if (a.dense_scores) a.dense_scores[((size_t)img * a.n_anchor + anchor) * a.dense_q + k] = sc;
+                if (sc > a.cand_thr) {
                     const unsigned id = (unsigned)anchor * YOLO_MAX_Q + (unsigned)k;
-                    a.cand[(size_t)img * a.cand_cap + slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (0xFFFFFFFFu - id);
+                    s_cand[atomicAdd(&s_n, 1)] = ((unsigned long long)__float_as_uint(sc) << 32) | (0xFFFFFFFFu - id);
                 }
             }
         }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (threadIdx.x == 0 && n > 0) s_base = atomicAdd(&a.cand_count[img], n);
+    __syncthreads();
+    if (n > 0) {
+        const int base = s_base;
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if (base + i < a.cand_cap) a.cand[(size_t)img * a.cand_cap + base + i] = s_cand[i];
     }
 }
 
@@ -677,7 +731,7 @@ int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, cons
     }
     for (int i = 0; i < n_levels; ++i) {
         YoloLevel l{h_levels[i * 8], h_levels[i * 8 + 1], h_levels[i * 8 + 2], h_levels[i * 8 + 3], h_levels[i * 8 + 4], 0.f, 0.f};
-        if (!buf_ok(l.e_buf) || !buf_ok(l.r_buf) || h->buf_c[l.e_buf] != YOLO_TEXT || h->buf_c[l.r_buf] != 4 * YOLO_REG_MAX ||
+        if (!buf_ok(l.e_buf) || !buf_ok(l.r_buf) || (l.size * l.size) % 16 != 0 || h->buf_c[l.e_buf] != YOLO_TEXT || h->buf_c[l.r_buf] != 4 * YOLO_REG_MAX ||
             h->buf_h[l.e_buf] != l.size || h->buf_h[l.r_buf] != l.size || !off_ok(l.param_off, 2)) {
             set_error("tstar_yolo_create: malformed head level"); return fail(TSTAR_ERR_ARG);
         }
@@ -871,7 +925,7 @@ int tstar_yolo_detect(tstar_yolo* h, const uint8_t* d_images, int B, int H, int 
             a.boxes = h->d_boxes; a.cand = h->d_cand; a.cand_cap = h->cand_cap; a.cand_count = h->d_cand_count;
             a.dense_scores = d_dense_scores ? d_dense_scores + (size_t)b0 * h->n_anchor * q_uniform : nullptr; a.dense_q = q_uniform;
             const int rows = Bc * a.HW;
-            hipLaunchKernelGGL(head_decode_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, a, rows);
+            hipLaunchKernelGGL(head_decode_kernel, dim3(cdiv(rows, HD_APB)), dim3(256), 0, s, a, rows);
             TSTAR_HIP_CHECK(hipGetLastError());
             anchor0 += a.HW;
         }
