@@ -492,13 +492,15 @@ def main():
     # timed process, so the per-launch figure measured with `tools/rocpd_traffic.py` is read from the
     # committed summary (profiles/); None if it has not been collected.
     traffic, traffic_src = None, None
-    tp = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
-    if os.path.isfile(tp):
-        try:
-            tj = json.load(open(tp))
-            traffic, traffic_src = tj["bytes_per_launch_corrected"], "profiles/r01_pmc_gemm_traffic.json"
-        except Exception:
-            pass
+    for tag in ("r02", "r01"):                     # the newest collection (tools/collect_profiles.sh) wins
+        tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_gemm_traffic.json")
+        if os.path.isfile(tp):
+            try:
+                tj = json.load(open(tp))
+                traffic, traffic_src = tj["bytes_per_launch_corrected"], f"profiles/{tag}_pmc_gemm_traffic.json"
+                break
+            except Exception:
+                pass
 
     # f32 weights: native f32 MFMA, algorithmic = executed flops.  bf16 weights: each algorithmic product is
     # three bf16 MFMA products (exact activation split), priced against the dense bf16 peak.

@@ -169,6 +169,11 @@ int tstar_frames_to_grid(const uint8_t* d_video, int N, int H, int W, const int3
  * out u8 [n,out_h,out_w,3]. */
 int tstar_frames_resize(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n,
                         int out_w, int out_h, uint8_t* d_out, int nv12, void* stream);
+/* Decode front end for RAW 4:2:0 containers (compressed streams need rocDecode / FFmpeg, which this
+ * build does not have): n planar I420 frames (Y, U, V planes back to back, H*W*3/2 bytes each) already copied to the
+ * device -> the resident NV12 store layout u8 [n, H*3/2, W] the ingest kernels read.  Replaces the decode half of
+ * read_frame_batch (interface_searcher.py:157-169) for such files. */
+int tstar_i420_to_nv12(const uint8_t* d_i420, int n, int H, int W, uint8_t* d_nv12, void* stream);
 /* Native-resolution RGB u8 [n,H,W,3] of NV12 frames (the keyframes pop_frames hands back, :379-380). */
 int tstar_nv12_to_rgb(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int n,
                       uint8_t* d_out, void* stream);

@@ -137,3 +137,44 @@ def test_create_image_grid_reference_method():
     assert grid.shape == (190, 600, 3) and np.array_equal(grid, ref)
     with pytest.raises(ValueError, match="Frame count does not match grid dimensions"):
         s.create_image_grid(frames[:5], 2, 3)
+
+
+def test_y4m_decode_front_end(tmp_path):
+    """SURVEY.md 8f-3, the part that is buildable here: a raw 4:2:0 file (YUV4MPEG2) is read once, staged through pinned
+    buffers and repacked I420 -> NV12 on the device into the resident store; the searcher's index map (raw frame
+    int(sec * fps), interface_searcher.py:360) selects the frames.  Bytes must equal the source frames', the ingest on the
+    loaded store must equal the ingest on the same frames built directly, and the searcher opens the path by name."""
+    from oracle import resize_ref as R
+    from tstar_amd import video as V
+    from tstar_amd.interface_searcher import TStarSearcher
+    import golden_util as GU
+    n_raw, H, W = 150, 72, 128
+    raw = V.synthetic_nv12_numpy(list(range(n_raw)), n_raw, H, W, seed=9)
+    path = str(tmp_path / "clip.y4m")
+    V.write_y4m(path, raw, fps=(30000, 1001))                             # 29.97 fps -> 5 logical seconds
+    hd = V.parse_y4m_header(path)
+    assert hd["n_frames"] == n_raw and abs(hd["fps"] - 29.97) < 0.01
+    st = V.open_video(path)
+    assert st.fmt == "nv12" and st.num_seconds == int(n_raw / hd["fps"]) == 5 and st.raw_total_frames == n_raw
+    want = [int(s * hd["fps"]) for s in range(5)]
+    assert np.array_equal(st.frames.cpu().numpy(), raw[want])
+    rgb = st.host_frames([0, 3])
+    assert np.array_equal(rgb[1], R.nv12_to_rgb(raw[want[3]]))
+    # chunking (more seconds than one staging chunk) and a 1 fps file
+    raw2 = V.synthetic_nv12_numpy(list(range(70)), 70, H, W, seed=10)
+    path2 = str(tmp_path / "long.y4m")
+    V.write_y4m(path2, raw2, fps=(1, 1))
+    st2 = V.load_y4m(path2, chunk=16)
+    assert st2.num_seconds == 70 and np.array_equal(st2.frames.cpu().numpy(), raw2)
+    h = GU.FakeHeuristic(0)
+    s = TStarSearcher(video_path=path2, heuristic=h, target_objects=["a"], cue_objects=[], search_nframes=4,
+                      image_grid_shape=(2, 2), search_budget=0.2, confidence_threshold=0.5, rng=np.random.RandomState(1))
+    frames, ts = s.search()
+    assert frames.shape == (4, H, W, 3) and s.total_frame_num == 70
+    for bad, msg in ((b"RIFF....", "not a YUV4MPEG2"), (b"YUV4MPEG2 W128 H72 F1:1 C444\nFRAME\n", "only 8-bit 4:2:0")):
+        pb = tmp_path / "bad.y4m"
+        pb.write_bytes(bad)
+        with pytest.raises(ValueError, match=msg):
+            V.open_video(str(pb))
+    with pytest.raises(ValueError, match="Cannot open video file"):
+        V.open_video(str(tmp_path / "missing.y4m"))

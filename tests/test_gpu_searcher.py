@@ -290,6 +290,36 @@ def test_l2_teacher_forced_bench_workload():
           f"max |score - oracle| grid {err_grid:.2e} / verify {err_ver:.2e}")
 
 
+def test_l2_teacher_forced_reference_default_grid():
+    """BASELINE configs[0]'s shape on the GPU -- the reference's DEFAULT 4x4 grid on the 3600-frame video: 63 iterations,
+    1008 grid frames, hundreds of verification calls, the FITPACK retry path on almost every fit -- teacher-forced: the
+    recorded confidences replayed through the oracle searcher give the same 63 sets of sampled seconds, the same
+    histories at every iteration and the same keyframes, bit for bit."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_video
+    N, g, K, seed = 3600, 4, 8, 2025
+    h = OWLInterface(synthetic_seed=0, max_batch=32)
+    rec = _Recorder(h)
+    s = TStarSearcher(synthetic_video(N, seed=0), h, ["couch"], ["tv", "chair"], search_nframes=K, image_grid_shape=(g, g),
+                      search_budget=1000, confidence_threshold=0.6, rng=np.random.RandomState(seed), keep_visual_history=False)
+    log = []
+    orig = s.sample_frames
+    s.sample_frames = lambda num: (lambda r: (log.append(list(r[0])), r)[1])(orig(num))
+    frames, ts = s.search()
+    assert s.iterations == 63 and len(log) == 63 and len(set(sum(log, []))) == 1008
+    ref, ts_ref = _replay_through_oracle(rec, h, ["couch"], ["tv", "chair"], N, g, K, 1000, 0.6, seed)
+    assert [it["secs"] for it in ref.trace] == log
+    assert ts_ref == [float(t) for t in ts]
+    for i in range(63):
+        assert np.array_equal(np.asarray(s.Score_history[i]), ref.Score_history[i]), i
+        assert np.array_equal(np.asarray(s.P_history[i]), ref.P_history[i]), i
+    assert np.array_equal(s.score_distribution, ref.score)
+    n_ver = sum(len(it["verify"]) for it in ref.trace)
+    assert s.detector_calls == 63 + n_ver and s.frames_scored == 63 * 16 + n_ver
+    print(f"reference-default grid teacher-forced: keyframes {ts_ref}, {n_ver} verification calls over 63 iterations")
+
+
 def test_generic_heuristic_path_matches_fast_path():
     """A foreign duck-typed heuristic (only the reference surface) must give the same search."""
     from tstar_amd.interface_searcher import TStarSearcher

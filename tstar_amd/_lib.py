@@ -41,6 +41,7 @@ SIGNATURES = {
     "tstar_yolo_detect": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tstar_frames_to_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "tstar_frames_resize": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "tstar_i420_to_nv12": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "tstar_nv12_to_rgb": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "tstar_searcher_create": (_i, [C.POINTER(_vp), _i, C.c_double, C.c_double]),
     "tstar_searcher_destroy": (_i, [_vp]),

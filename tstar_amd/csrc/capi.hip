@@ -502,6 +502,11 @@ int tstar_nv12_to_rgb(const uint8_t* d_video, int N, int H, int W, const int32_t
     return nv12_to_rgb_u8(d_video, H, W, d_frame_idx, n, d_out, (hipStream_t)stream);
 }
 
+int tstar_i420_to_nv12(const uint8_t* d_i420, int n, int H, int W, uint8_t* d_nv12, void* stream) {
+    TSTAR_REQUIRE(d_i420 && d_nv12 && d_i420 != d_nv12, "tstar_i420_to_nv12: null or aliased argument");
+    return i420_to_nv12_u8(d_i420, n, H, W, d_nv12, (hipStream_t)stream);
+}
+
 int tstar_gemm_f32(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
                    int N, int K, int act, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32: null argument");

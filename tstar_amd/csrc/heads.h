@@ -56,6 +56,8 @@ int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int
 // frames[idx[i]] -> (4*ch x 4*cw) -> (ch x cw) -> tile (i / cols, i % cols) of grid [rows*ch, cols*cw, 3]
 int frames_to_grid_u8(const uint8_t* video, int H, int W, const int* d_idx, int rows, int cols, int cw, int ch,
                       uint8_t* grid, int nv12, hipStream_t s);
+// n planar I420 frames [H*3/2*W bytes each: Y, U, V planes] -> NV12 [n, H*3/2, W]
+int i420_to_nv12_u8(const uint8_t* in, int n, int H, int W, uint8_t* out, hipStream_t s);
 // frames[idx[i]] NV12 [H*3/2, W] -> RGB u8 [n,H,W,3] (BT.601 limited range, nearest chroma)
 int nv12_to_rgb_u8(const uint8_t* video, int H, int W, const int* d_idx, int n, uint8_t* out, hipStream_t s);
 

@@ -349,6 +349,40 @@ __global__ __launch_bounds__(256) void nv12_to_rgb_kernel(const uint8_t* __restr
     d[0] = (uint8_t)v.r; d[1] = (uint8_t)v.g; d[2] = (uint8_t)v.b;
 }
 
+// planar I420 (Y plane, U plane, V plane: what raw 4:2:0 containers such as YUV4MPEG2 carry) -> NV12 (Y plane + interleaved
+// UV plane) for n frames; 16 bytes of luma / 8 chroma pairs per lane.  Pure byte movement, HBM-bound.
+__global__ __launch_bounds__(256) void i420_to_nv12_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int W, size_t total16) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total16) return;
+    const size_t fb = (size_t)H * W * 3 / 2, per = fb / 16;            // 16-byte units per frame
+    const size_t f = gid / per, u = gid % per;
+    const uint8_t* src = in + f * fb;
+    uint8_t* dst = out + f * fb;
+    const size_t ybytes = (size_t)H * W;
+    if (u * 16 < ybytes) {
+        *reinterpret_cast<uint4*>(dst + u * 16) = *reinterpret_cast<const uint4*>(src + u * 16);
+    } else {
+        const size_t c0 = (u * 16 - ybytes) / 2;                        // first chroma sample of this unit
+        const uint8_t* pu = src + ybytes + c0;
+        const uint8_t* pv = src + ybytes + ybytes / 4 + c0;
+        const uint2 uu = *reinterpret_cast<const uint2*>(pu), vv = *reinterpret_cast<const uint2*>(pv);
+        const uint8_t* ub = reinterpret_cast<const uint8_t*>(&uu);
+        const uint8_t* vb = reinterpret_cast<const uint8_t*>(&vv);
+        uint8_t o[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { o[2 * i] = ub[i]; o[2 * i + 1] = vb[i]; }
+        *reinterpret_cast<uint4*>(dst + u * 16) = *reinterpret_cast<const uint4*>(o);
+    }
+}
+
+int i420_to_nv12_u8(const uint8_t* in, int n, int H, int W, uint8_t* out, hipStream_t s) {
+    TSTAR_REQUIRE(n > 0 && H % 2 == 0 && W % 2 == 0 && ((size_t)H * W) % 64 == 0, "i420_to_nv12_u8: needs even dimensions with H * W a multiple of 64");
+    const size_t total16 = (size_t)n * H * W * 3 / 2 / 16;
+    hipLaunchKernelGGL(i420_to_nv12_kernel, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, in, out, H, W, total16);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
 int nv12_to_rgb_u8(const uint8_t* video, int H, int W, const int* d_idx, int n, uint8_t* out, hipStream_t s) {
     TSTAR_REQUIRE(n > 0 && H % 2 == 0 && W % 2 == 0, "nv12_to_rgb_u8: NV12 needs even dimensions");
     const size_t total = (size_t)n * H * W;

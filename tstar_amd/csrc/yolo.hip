@@ -23,6 +23,7 @@
 #include "heads.h"
 #include "prof.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -52,17 +53,24 @@ struct ConvArgs {
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
 // ------------------------------------------------------------------ implicit-GEMM conv on the VALU
-constexpr int CBM = 128, CBN = 64, CBK = 16, CLD_A = CBM + 4, CLD_W = CBN + 4;
+// Workgroup tile 128 pixels x BN channels (BN = 64 or 128), K slices of 16; a lane owns 8 pixels x TN channels (TN = 4
+// or 8).  Per k the lane reads 2 + TN/4 LDS quads for 8 TN FMAs: with TN = 8 the LDS pipe (shared by the CU's four
+// SIMDs) carries 4 reads per 64 FMAs instead of 3 per 32, which is what keeps the VALU fed on the >= 128-channel layers.
+// LDS rows k >= 8 are rotated by 8 floats: the transposing ds_write_b32 of lanes with k-quad 0 / 2 (and 1 / 3) would
+// otherwise land on the same banks (row stride = 16 mod 32 banks); the b128 fragment reads stay 16-byte aligned.
+constexpr int CBM = 128, CBK = 16, CLD_A = CBM + 4;
 
-template <int KS>
+template <int KS, int TN>
 __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a) {
+    constexpr int BN = 16 * TN, CLD_W = BN + 4, NWQ = BN / 64;       // NWQ weight float4 per thread per slice
     __shared__ __attribute__((aligned(16))) float As[CBK][CLD_A];
     __shared__ __attribute__((aligned(16))) float Ws[CBK][CLD_W];
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.x * CBM, n0 = blockIdx.y * CBN;
+    const int m0 = blockIdx.x * CBM, n0 = blockIdx.y * BN;
     // staging roles: A tile 128 x 16 = 512 float4 -> 2 per thread (rows tid/4 and tid/4 + 64, k quad tid%4);
-    //                W tile  64 x 16 = 256 float4 -> 1 per thread
+    //                W tile  BN x 16 -> NWQ per thread (rows tid/4 (+64))
     const int kq = (tid & 3) * 4;
+    const int rot = (kq >> 3) * 8;                                   // column rotation of LDS rows k >= 8
     const int ar0 = tid >> 2;
     int ab[2], ay[2], ax[2];
     bool aval[2];
@@ -77,20 +85,25 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a) {
         ay[r] = (rem / a.Wo) * a.stride - (KS >> 1);
         ax[r] = (rem % a.Wo) * a.stride - (KS >> 1);
     }
-    const int wn = n0 + (tid >> 2);
-    const bool wval = wn < a.cout;
     const int K = KS * KS * a.cin;
-    const float* wrow = a.w + (size_t)(wval ? wn : 0) * K + kq;
+    const float* wrow[NWQ];
+    bool wval[NWQ];
+#pragma unroll
+    for (int r = 0; r < NWQ; ++r) {
+        const int wn = n0 + ar0 + r * 64;
+        wval[r] = wn < a.cout;
+        wrow[r] = a.w + (size_t)(wval[r] ? wn : 0) * K + kq;
+    }
 
-    // compute roles: 8 rows x 4 cols per lane
-    const int tx = tid & 15, ty = tid >> 4;                  // cols tx*4.., rows ty*8..
-    float acc[8][4];
+    // compute roles: 8 rows x TN cols per lane
+    const int tx = tid & 15, ty = tid >> 4;                          // cols tx*4 (+64).., rows ty*8..
+    float acc[8][TN];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
 
-    f32x4 ra[2], rw;
+    f32x4 ra[2], rw[NWQ];
     auto load_tile = [&](int k0) {
         // k0 is a multiple of 16 and cin % 16 == 0, so the 16-wide slice stays inside one (ky, kx) tap
         const int tap = k0 / a.cin;
@@ -104,17 +117,22 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a) {
             if (ok) v = *reinterpret_cast<const f32x4*>(a.src + ((size_t)(ab[r] * a.H + iy) * a.W + ix) * a.src_ld + a.src_off + ci);
             ra[r] = v;
         }
-        f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        if (wval) w = *reinterpret_cast<const f32x4*>(wrow + k0);
-        rw = w;
+#pragma unroll
+        for (int r = 0; r < NWQ; ++r) {
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (wval[r]) w = *reinterpret_cast<const f32x4*>(wrow[r] + k0);
+            rw[r] = w;
+        }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[kq + e][ar0 + r * 64] = ra[r][e];
+            for (int e = 0; e < 4; ++e) As[kq + e][(ar0 + r * 64 + rot) & (CBM - 1)] = ra[r][e];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Ws[kq + e][tid >> 2] = rw[e];
+        for (int r = 0; r < NWQ; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ws[kq + e][(ar0 + r * 64 + rot) & (BN - 1)] = rw[r][e];
     };
 
     load_tile(0);
@@ -125,46 +143,54 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a) {
         if (k0 + CBK < K) load_tile(k0 + CBK);               // global loads of the next slice fly during the FMAs
 #pragma unroll
         for (int k = 0; k < CBK; ++k) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[k][ty * 8]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[k][ty * 8 + 4]);
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Ws[k][tx * 4]);
+            const int rk = (k >> 3) * 8;                             // compile-time after unrolling
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[k][(ty * 8 + rk) & (CBM - 1)]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[k][(ty * 8 + 4 + rk) & (CBM - 1)]);
+            f32x4 w4[TN / 4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int q = 0; q < TN / 4; ++q) w4[q] = *reinterpret_cast<const f32x4*>(&Ws[k][(tx * 4 + q * 64 + rk) & (BN - 1)]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[i][j] = fmaf(a0[i], w4[j], acc[i][j]);
-                    acc[4 + i][j] = fmaf(a1[i], w4[j], acc[4 + i][j]);
+            for (int q = 0; q < TN / 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i][q * 4 + j] = fmaf(a0[i], w4[q][j], acc[i][q * 4 + j]);
+                        acc[4 + i][q * 4 + j] = fmaf(a1[i], w4[q][j], acc[4 + i][q * 4 + j]);
+                    }
                 }
-            }
         }
     }
     // epilogue: bias, activation, residual (after the activation: DarknetBottleneck adds the identity last) or the
     // max-sigmoid attention gate (after project_conv's BatchNorm, no activation)
-    const int nb = n0 + tx * 4;
-    if (nb >= a.cout) return;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + nb);
     const int ch_per_head = a.mode == MODE_ATTN_MUL ? a.cout / a.heads : 1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + ty * 8 + i;
-        if (m >= a.M) continue;
-        f32x4 v;
+    for (int q = 0; q < TN / 4; ++q) {
+        const int nb = n0 + tx * 4 + q * 64;
+        if (nb >= a.cout) continue;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + nb);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float t = acc[i][j] + bias[j];
-            if (a.act == YACT_SILU) t = silu(t);
-            v[j] = t;
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + ty * 8 + i;
+            if (m >= a.M) continue;
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[i][q * 4 + j] + bias[j];
+                if (a.act == YACT_SILU) t = silu(t);
+                v[j] = t;
+            }
+            if (a.mode == MODE_RESIDUAL) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(a.aux + (size_t)m * a.aux_ld + a.aux_off + nb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += r[j];
+            } else if (a.mode == MODE_ATTN_MUL) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= a.aux[(size_t)m * a.aux_ld + a.aux_off + (nb + j) / ch_per_head];
+            }
+            *reinterpret_cast<f32x4*>(a.dst + (size_t)m * a.dst_ld + a.dst_off + nb) = v;
         }
-        if (a.mode == MODE_RESIDUAL) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(a.aux + (size_t)m * a.aux_ld + a.aux_off + nb);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += r[j];
-        } else if (a.mode == MODE_ATTN_MUL) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= a.aux[(size_t)m * a.aux_ld + a.aux_off + (nb + j) / ch_per_head];
-        }
-        *reinterpret_cast<f32x4*>(a.dst + (size_t)m * a.dst_ld + a.dst_off + nb) = v;
     }
 }
 
@@ -241,11 +267,14 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     TSTAR_REQUIRE(a.cout % 4 == 0 && a.dst_ld % 4 == 0 && a.dst_off % 4 == 0, "yolo conv: output channels must be 16-byte aligned");
     const bool tiled = a.cin % CBK == 0 && a.src_ld % 4 == 0 && a.src_off % 4 == 0 && (a.ks == 1 || a.ks == 3);
     if (tiled) {
-        const dim3 grid(cdiv(a.M, CBM), cdiv(a.cout, CBN));
+        // 128-channel tiles (8 x 8 outputs per lane) when the layer has the channels and enough pixels to fill the chip
+        static const int tn_env = [] { const char* e = getenv("TSTAR_YOLO_TN"); return e ? atoi(e) : 0; }();
+        const bool wide = tn_env ? tn_env == 8 : (a.cout % 128 == 0 && (long long)cdiv(a.M, CBM) * (a.cout / 128) >= 512);
+        const dim3 grid(cdiv(a.M, CBM), cdiv(a.cout, wide ? 128 : 64));
         const bool prof = prof_enabled();
         if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
-        if (a.ks == 1) hipLaunchKernelGGL(conv_valu_kernel<1>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(conv_valu_kernel<3>, grid, dim3(256), 0, s, a);
+        if (a.ks == 1) { if (wide) hipLaunchKernelGGL((conv_valu_kernel<1, 8>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_valu_kernel<1, 4>), grid, dim3(256), 0, s, a); }
+        else { if (wide) hipLaunchKernelGGL((conv_valu_kernel<3, 8>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_valu_kernel<3, 4>), grid, dim3(256), 0, s, a); }
         if (prof) prof_stop(PROF_CONV, s);
     } else {
         TSTAR_REQUIRE(a.mode == MODE_PLAIN, "yolo conv: the direct form has no fused residual / gate");
@@ -488,91 +517,169 @@ __global__ __launch_bounds__(256) void head_decode_kernel(DecodeArgs a, int rows
     }
 }
 
-// One workgroup per image: sort candidates by (score desc, (anchor, class) asc), keep the first nms_pre, class-aware greedy
-// NMS by ONE wave, cut at max_per_img, clamp, then the wrapper's filter (score > thr, first max_dets of the sorted survivors).
+// One workgroup per image.  mmyolo's order of business -- every (anchor, class) pair with score > 0.001 is a candidate,
+// sorted by descending score, the first nms_pre = 30000 kept, class-aware NMS with mmcv's coordinate-offset trick (the offset
+// is the largest coordinate among ALL kept candidates + 1), max_per_img = 300, clamp -- followed by the reference wrapper
+// (score > 0.12, top max_dets).  Only candidates above the wrapper threshold can ever be output, and a candidate can only
+// be suppressed by a higher-scoring survivor, so the full sort is not needed:
+//   1. if there are more than nms_pre candidates, an 8-pass radix select finds the nms_pre-th largest key (keys are unique);
+//   2. the largest coordinate is reduced over the candidates at or above that key;
+//   3. the candidates above the wrapper threshold (and the cut) are compacted into LDS (up to 16384 keys = 128 KB) and
+//      bitonic-sorted there -- a global-memory sort of all 8400 x Q keys took 3.6 ms per batch; beyond 16384 the kernel
+//      falls back to sorting the whole list in global memory;
+//   4. greedy NMS by ONE wavefront (survivors in LDS, lanes test them in parallel, __ballot decides), cut, clamp, top-k.
+constexpr int NMS_LDS_KEYS = 16384;
 __global__ __launch_bounds__(1024) void sort_nms_kernel(unsigned long long* __restrict__ cand_all, int cand_cap, const int* __restrict__ cand_count,
                                                         const float* __restrict__ boxes_all, int n_anchor, float img_w, float img_h,
                                                         float wrapper_thr, int max_dets, float* __restrict__ det_scores,
                                                         int* __restrict__ det_labels, float* __restrict__ det_boxes, int* __restrict__ n_det) {
+    extern __shared__ unsigned long long s_keys[];             // NMS_LDS_KEYS
     __shared__ float k_box[YOLO_MAX_PER_IMG][4];               // offset boxes of the survivors
     __shared__ float k_area[YOLO_MAX_PER_IMG];
     __shared__ unsigned k_id[YOLO_MAX_PER_IMG];
     __shared__ float k_score[YOLO_MAX_PER_IMG];
     __shared__ float s_red[1024 / 64];
-    __shared__ int s_kept;
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned long long s_pref[2];
+    __shared__ int s_kept, s_m;
     const int img = blockIdx.x, t = threadIdx.x;
     unsigned long long* cand = cand_all + (size_t)img * cand_cap;
     const float* boxes = boxes_all + (size_t)img * n_anchor * 4;
     int n = cand_count[img];
     n = n < cand_cap ? n : cand_cap;
-    int n2 = 1;
-    while (n2 < n) n2 <<= 1;
-    for (int i = n + t; i < n2; i += 1024) cand[i] = 0ull;     // padding sorts last (score bits 0)
-    __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1) {                        // bitonic sort, descending
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < n2; i += 1024) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = cand[i], b = cand[l];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? a < b : a > b) { cand[i] = b; cand[l] = a; }
-                }
+    // ---- 1. the nms_pre cut: key of rank nms_pre - 1 in descending order (0 = no cut)
+    unsigned long long kth = 0ull;
+    if (n > YOLO_NMS_PRE) {
+        unsigned long long prefix = 0ull, mask = 0ull;
+        int kk = YOLO_NMS_PRE - 1;                             // rank from the top
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int i = t; i < 256; i += 1024) s_hist[i] = 0u;
+            __syncthreads();
+            for (int i = t; i < n; i += 1024) {
+                const unsigned long long c = cand[i];
+                if ((c & mask) == prefix) atomicAdd(&s_hist[(c >> shift) & 0xFF], 1u);
             }
             __syncthreads();
+            if (t == 0) {
+                int acc = 0, d = 255;
+                for (; d >= 0; --d) { if (acc + (int)s_hist[d] > kk) break; acc += s_hist[d]; }
+                s_pref[0] = prefix | ((unsigned long long)d << shift);
+                s_pref[1] = (unsigned long long)(kk - acc);
+            }
+            __syncthreads();
+            prefix = s_pref[0];
+            kk = (int)s_pref[1];
+            mask |= 0xFFULL << shift;
+            __syncthreads();
         }
+        kth = prefix;
     }
-    const int m = n < YOLO_NMS_PRE ? n : YOLO_NMS_PRE;
-    // mmcv batched_nms: boxes + label * (max coordinate + 1), in float32
+    // ---- 2. mmcv batched_nms: boxes + label * (max coordinate + 1), in float32; 3. compaction into LDS
+    if (t == 0) { s_kept = 0; s_m = 0; }
+    __syncthreads();
     float mx = -INFINITY;
-    for (int i = t; i < m; i += 1024) {
-        const unsigned id = 0xFFFFFFFFu - (unsigned)(cand[i] & 0xFFFFFFFFu);
+    for (int i = t; i < n; i += 1024) {
+        const unsigned long long c = cand[i];
+        if (c < kth) continue;
+        const unsigned id = 0xFFFFFFFFu - (unsigned)(c & 0xFFFFFFFFu);
         const f32x4 b = *reinterpret_cast<const f32x4*>(boxes + (size_t)(id / YOLO_MAX_Q) * 4);
         mx = fmaxf(fmaxf(fmaxf(mx, b[0]), fmaxf(b[1], b[2])), b[3]);
+        if (__uint_as_float((unsigned)(c >> 32)) > wrapper_thr) {
+            const int slot = atomicAdd(&s_m, 1);
+            if (slot < NMS_LDS_KEYS) s_keys[slot] = c;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((t & 63) == 0) s_red[t >> 6] = mx;
-    if (t == 0) s_kept = 0;
     __syncthreads();
     float maxc = s_red[0];
     for (int i = 1; i < 1024 / 64; ++i) maxc = fmaxf(maxc, s_red[i]);
     const float off_unit = maxc + 1.0f;
-    if (t < 64) {                                              // ONE wave: lock-step, no barriers
-        int kept = 0;
-        for (int i = 0; i < m && kept < YOLO_MAX_PER_IMG; ++i) {
-            const unsigned long long c = cand[i];
-            // the wrapper drops survivors at or below its threshold, and they cannot suppress anything before them
-            if (!(__uint_as_float((unsigned)(c >> 32)) > wrapper_thr)) break;
-            const unsigned id = 0xFFFFFFFFu - (unsigned)(c & 0xFFFFFFFFu);
-            const int label = (int)(id % YOLO_MAX_Q);
-            const f32x4 rb = *reinterpret_cast<const f32x4*>(boxes + (size_t)(id / YOLO_MAX_Q) * 4);
-            const float o = (float)label * off_unit;
-            const float x0 = rb[0] + o, y0 = rb[1] + o, x1 = rb[2] + o, y1 = rb[3] + o;
-            const float area = (x1 - x0) * (y1 - y0);
-            bool sup = false;
-            for (int j = t; j < kept; j += 64) {
-                const float iw = fmaxf(fminf(x1, k_box[j][2]) - fmaxf(x0, k_box[j][0]), 0.f);
-                const float ih = fmaxf(fminf(y1, k_box[j][3]) - fmaxf(y0, k_box[j][1]), 0.f);
-                const float inter = iw * ih;
-                sup |= inter / (area + k_area[j] - inter) > YOLO_IOU_THR;
-            }
-            if (__ballot(sup) == 0ull) {
-                if (t == 0) {
-                    k_box[kept][0] = x0; k_box[kept][1] = y0; k_box[kept][2] = x1; k_box[kept][3] = y1;
-                    k_area[kept] = area; k_id[kept] = id; k_score[kept] = __uint_as_float((unsigned)(c >> 32));
+    int m = s_m;
+    unsigned long long* keys = s_keys;
+    if (m > NMS_LDS_KEYS) {                                    // rare: sort the whole list in global memory instead
+        keys = cand;
+        int n2 = 1;
+        while (n2 < n) n2 <<= 1;
+        for (int i = n + t; i < n2; i += 1024) cand[i] = 0ull;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < n2; i += 1024) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long x = cand[i], y = cand[l];
+                        if (((i & k) == 0) ? x < y : x > y) { cand[i] = y; cand[l] = x; }
+                    }
                 }
-                ++kept;
+                __syncthreads();
+            }
+        m = n < YOLO_NMS_PRE ? n : YOLO_NMS_PRE;
+    } else {
+        int n2 = 1;
+        while (n2 < m) n2 <<= 1;
+        for (int i = m + t; i < n2; i += 1024) s_keys[i] = 0ull;          // padding sorts last (score bits 0)
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1)                                   // bitonic sort in LDS, descending
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < n2; i += 1024) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long x = s_keys[i], y = s_keys[l];
+                        if (((i & k) == 0) ? x < y : x > y) { s_keys[i] = y; s_keys[l] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    if (t < 64) {                                              // ---- 4. ONE wave: lock-step, no barriers
+        // candidates are taken 64 at a time: every lane fetches one candidate's key and box (64 independent loads in flight),
+        // then the wave walks them in order with v_readlane broadcasts -- a dependent global load per candidate cost ~1.5 us
+        int kept = 0;
+        bool done = false;
+        for (int base = 0; base < m && kept < YOLO_MAX_PER_IMG && !done; base += 64) {
+            const int mine = base + t;
+            const unsigned long long cm = mine < m ? keys[mine] : 0ull;
+            const unsigned idm = 0xFFFFFFFFu - (unsigned)(cm & 0xFFFFFFFFu);
+            f32x4 bm = {0.f, 0.f, 0.f, 0.f};
+            if (mine < m) bm = *reinterpret_cast<const f32x4*>(boxes + (size_t)(idm / YOLO_MAX_Q) * 4);
+            const int scm = (int)(unsigned)(cm >> 32);
+            const int cnt = (m - base) < 64 ? (m - base) : 64;
+            for (int j = 0; j < cnt && kept < YOLO_MAX_PER_IMG; ++j) {
+                const float sc = __int_as_float(__builtin_amdgcn_readlane(scm, j));
+                // the wrapper drops survivors at or below its threshold, and they cannot suppress anything before them
+                if (!(sc > wrapper_thr)) { done = true; break; }
+                const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)idm, j);
+                const int label = (int)(id % YOLO_MAX_Q);
+                const float o = (float)label * off_unit;
+                const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bm[0]), j)) + o;
+                const float y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bm[1]), j)) + o;
+                const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bm[2]), j)) + o;
+                const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bm[3]), j)) + o;
+                const float area = (x1 - x0) * (y1 - y0);
+                bool sup = false;
+                for (int q = t; q < kept; q += 64) {
+                    const float iw = fmaxf(fminf(x1, k_box[q][2]) - fmaxf(x0, k_box[q][0]), 0.f);
+                    const float ih = fmaxf(fminf(y1, k_box[q][3]) - fmaxf(y0, k_box[q][1]), 0.f);
+                    const float inter = iw * ih;
+                    sup |= inter / (area + k_area[q] - inter) > YOLO_IOU_THR;
+                }
+                if (__ballot(sup) == 0ull) {
+                    if (t == 0) {
+                        k_box[kept][0] = x0; k_box[kept][1] = y0; k_box[kept][2] = x1; k_box[kept][3] = y1;
+                        k_area[kept] = area; k_id[kept] = id; k_score[kept] = sc;
+                    }
+                    ++kept;
+                }
             }
         }
         if (t == 0) s_kept = kept;
     }
     __syncthreads();
-    // survivors are in descending score order: the wrapper's "score > thr, then top max_dets" is a prefix
+    // survivors are in descending score order and all above the wrapper threshold: the output is a prefix
     const int kept = s_kept;
-    int nd = 0;
-    for (int i = 0; i < kept && i < max_dets; ++i) nd += k_score[i] > wrapper_thr;
-    // (scores descend, so the survivors above the threshold are the first nd)
+    const int nd = kept < max_dets ? kept : max_dets;
     if (t < max_dets) {
         float* b = det_boxes + ((size_t)img * max_dets + t) * 4;
         if (t < nd) {
@@ -929,7 +1036,8 @@ int tstar_yolo_detect(tstar_yolo* h, const uint8_t* d_images, int B, int H, int 
             TSTAR_HIP_CHECK(hipGetLastError());
             anchor0 += a.HW;
         }
-        hipLaunchKernelGGL(sort_nms_kernel, dim3(Bc), dim3(1024), 0, s, h->d_cand, h->cand_cap, h->d_cand_count, h->d_boxes, h->n_anchor,
+        RC(ensure_dyn_lds(reinterpret_cast<const void*>(sort_nms_kernel), NMS_LDS_KEYS * 8));
+        hipLaunchKernelGGL(sort_nms_kernel, dim3(Bc), dim3(1024), (size_t)NMS_LDS_KEYS * 8, s, h->d_cand, h->cand_cap, h->d_cand_count, h->d_boxes, h->n_anchor,
                            (float)W, (float)H, score_threshold, max_dets, d_det_scores + (size_t)b0 * max_dets, d_det_labels + (size_t)b0 * max_dets,
                            d_det_boxes + (size_t)b0 * max_dets * 4, d_n_det + b0);
         TSTAR_HIP_CHECK(hipGetLastError());

@@ -5,8 +5,10 @@ The reference re-opens the file with decord on every read
 frame count (:60-65).  Here a video is decoded ONCE into a uint8 tensor
 [N,H,W,3] (RGB) on the GPU and every later gather/resize is a HIP kernel
 (tstar_frames_to_grid / tstar_frames_resize).  Decode itself (FFmpeg/VCN) is
-outside the hot path (SURVEY.md 8f "next" row 3); real files need decord or cv2
-on the host, synthetic videos need nothing.
+outside the hot path (SURVEY.md 8f "next" row 3): raw 4:2:0 files (YUV4MPEG2) are
+read and repacked on the device here (``load_y4m``); compressed files need decord
+or cv2 on the host (rocDecode / FFmpeg are not in this build), synthetic videos
+need nothing.
 """
 from __future__ import annotations
 
@@ -172,6 +174,96 @@ def load_video_frames(video, num_frames: int = 8) -> np.ndarray:
     return st.host_frames([min(last, max(0, int(round(r / st.raw_fps)))) for r in raw])
 
 
+def parse_y4m_header(path: str):
+    """YUV4MPEG2 stream header -> dict(w, h, fps (float), fps_frac (num, den), chroma, data_offset, frame_bytes,
+    frame_header_bytes, n_frames).  8-bit 4:2:0 only (C420, C420jpeg, C420mpeg2, C420paldv or no C tag)."""
+    import os
+    with open(path, "rb") as f:
+        head = f.readline(4096)
+        if not head.startswith(b"YUV4MPEG2 ") or not head.endswith(b"\n"):
+            raise ValueError(f"Cannot open video file: {path} (not a YUV4MPEG2 stream)")
+        tags = head[len(b"YUV4MPEG2 "):-1].split(b" ")
+        kv = {t[:1].decode(): t[1:].decode() for t in tags if t}
+        try:
+            w, h = int(kv["W"]), int(kv["H"])
+            num, den = (int(v) for v in kv.get("F", "25:1").split(":"))
+        except (KeyError, ValueError):
+            raise ValueError(f"Cannot open video file: {path} (malformed YUV4MPEG2 header)")
+        chroma = kv.get("C", "420jpeg")
+        if chroma not in ("420", "420jpeg", "420mpeg2", "420paldv"):
+            raise ValueError(f"Cannot open video file: {path} (only 8-bit 4:2:0 YUV4MPEG2 is supported, got C{chroma})")
+        if w % 2 or h % 2 or den <= 0 or num <= 0:
+            raise ValueError(f"Cannot open video file: {path} (odd dimensions or bad frame rate)")
+        off = f.tell()
+        fh = f.readline(256)
+        if not fh.startswith(b"FRAME"):
+            raise ValueError(f"Cannot open video file: {path} (no FRAME marker)")
+    fb = w * h * 3 // 2
+    size = os.path.getsize(path)
+    # every frame header of the streams we accept is the plain marker read above (parameters would change its length)
+    n = (size - off) // (len(fh) + fb)
+    return dict(w=w, h=h, fps=num / den, fps_frac=(num, den), chroma=chroma, data_offset=off, frame_bytes=fb,
+                frame_header_bytes=len(fh), n_frames=int(n))
+
+
+def load_y4m(path: str, device: str = "cuda", chunk: int = 64) -> FrameStore:
+    """Decode front end for raw 4:2:0 video: a YUV4MPEG2 file is read ONCE, the frames the searcher can ever
+    ask for (raw frame int(sec * fps) for every logical second, interface_searcher.py:360) are staged through two pinned
+    host buffers, copied to HBM on a side stream and repacked I420 -> NV12 by a HIP kernel (tstar_i420_to_nv12) straight into
+    the resident store, the host read of the next chunk overlapping the copy of the previous one.  Replaces the
+    reopen-and-seek-per-call decord reader (:157-169) for such files; compressed streams would need rocDecode / FFmpeg,
+    which this build does not have."""
+    import torch
+    from . import _lib
+    hd = parse_y4m_header(path)
+    w, h, fb = hd["w"], hd["h"], hd["frame_bytes"]
+    n_sec = int(hd["n_frames"] / hd["fps"])
+    if n_sec < 1:
+        raise ValueError(f"Cannot open video file: {path} (shorter than one second)")
+    want = [int(sec * hd["fps"]) for sec in range(n_sec)]
+    lib = _lib.load()
+    store = torch.empty((n_sec, h * 3 // 2, w), dtype=torch.uint8, device=device)
+    pinned = [torch.empty((chunk, fb), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    staged = [torch.empty((chunk, fb), dtype=torch.uint8, device=device) for _ in range(2)]
+    done = [None, None]
+    side = torch.cuda.Stream()
+    stride = hd["frame_header_bytes"] + fb
+    with open(path, "rb") as f:
+        for ci, s0 in enumerate(range(0, n_sec, chunk)):
+            b = ci & 1
+            if done[b] is not None:
+                done[b].synchronize()                     # the pinned buffer's previous copy has left
+            idx = want[s0:s0 + chunk]
+            host = pinned[b].numpy()
+            for j, fi in enumerate(idx):
+                f.seek(hd["data_offset"] + fi * stride + hd["frame_header_bytes"])
+                got = f.readinto(memoryview(host[j]))
+                if got != fb:
+                    raise ValueError(f"Cannot open video file: {path} (truncated at frame {fi})")
+            with torch.cuda.stream(side):
+                staged[b][:len(idx)].copy_(pinned[b][:len(idx)], non_blocking=True)
+                _lib.check(lib.tstar_i420_to_nv12(staged[b].data_ptr(), len(idx), h, w, store[s0:s0 + len(idx)].data_ptr(),
+                                                  side.cuda_stream), "tstar_i420_to_nv12")
+                done[b] = torch.cuda.Event()
+                done[b].record(side)
+    side.synchronize()
+    return FrameStore(store, hd["fps"], hd["n_frames"], name=path, fmt="nv12")
+
+
+def write_y4m(path: str, nv12_frames: np.ndarray, fps=(1, 1)) -> None:
+    """uint8 [n, H*3/2, W] NV12 frames -> a YUV4MPEG2 file (planar I420 payload).  Test / example helper."""
+    n, h32, w = nv12_frames.shape
+    h = h32 * 2 // 3
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{w} H{h} F{fps[0]}:{fps[1]} Ip A1:1 C420mpeg2\n".encode())
+        for fr in nv12_frames:
+            uv = fr[h:].reshape(h // 2, w // 2, 2)
+            f.write(b"FRAME\n")
+            f.write(fr[:h].tobytes())
+            f.write(np.ascontiguousarray(uv[..., 0]).tobytes())
+            f.write(np.ascontiguousarray(uv[..., 1]).tobytes())
+
+
 _SYN = re.compile(r"^synthetic://")
 
 
@@ -189,6 +281,11 @@ def open_video(video, device: str = "cuda") -> FrameStore:
         return synthetic_video(int(kv.get("n", 3600)), int(kv.get("h", 360)), int(kv.get("w", 640)),
                                int(kv.get("seed", 0)), float(kv.get("fps", 1.0)), device)
     import torch
+    if isinstance(video, str) and video.lower().endswith(".y4m"):
+        import os
+        if not os.path.isfile(video):
+            raise ValueError(f"Cannot open video file: {video}")
+        return load_y4m(video, device)
     try:
         from decord import VideoReader, cpu  # type: ignore
         vr = VideoReader(video, ctx=cpu(0))
