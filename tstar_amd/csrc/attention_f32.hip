@@ -26,7 +26,14 @@
 //    workgroups that tile the 576 patch queries exactly (92 / 67 TFLOP/s vs 118 for 4 waves:
 //    more K/V staging per MFMA, no SIMD imbalance to win back -- a workgroup's waves land on
 //    the SIMDs cyclically from a varying start); the straggler query 576 in its own VALU-only
-//    workgroup (-15 %: it re-reads all K/V of its head, 20 % more L2 traffic).
+//    workgroup (-15 %: it re-reads all K/V of its head, 20 % more L2 traffic); K/V tiles by direct
+//    global -> LDS DMA (global_load_lds_dwordx4 through inline asm, no staging VGPRs / ds_write:
+//    114.4 vs 114.6 in a same-session A/B -- no gain); the same plus scalar-base addressing, a loop
+//    unrolled over the two LDS buffers and a subtract-free softmax (accumulator started at -max):
+//    107 (register spills).  Ablations of the adopted kernel at B = 256: no barrier +-0, no K/V
+//    reloads +7 %, no exp / sub / add in the softmax +3.6 %: no single limiter is left; the rest is
+//    the MFMA issue pattern (one dependent 32-MFMA chain for S^T, two chains for PV, LDS fragment
+//    reads between them) against 4 independent chains in the GEMM tile.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
