@@ -506,8 +506,14 @@ def main():
     # three bf16 MFMA products (exact activation split), priced against the dense bf16 peak.
     bound = "mfma"
     if args.heuristic == "yolo":
-        gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel (implicit-GEMM convolution, v_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
+        gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel (implicit-GEMM convolution, v_pk_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
         traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r02_yolo_pmc_conv_traffic.json")     # tools/collect_yolo_profiles.sh (32-image batch)
+        if os.path.isfile(tp):
+            try:
+                traffic, traffic_src = json.load(open(tp))["bytes_per_launch_corrected"], "profiles/r02_yolo_pmc_conv_traffic.json"
+            except Exception:
+                pass
     elif args.weights in ("bf16", "f32_split"):
         gemm_kernel, peak, exec_mult = f"gemm_f32_kernel<WMODE={1 if args.weights == 'bf16' else 2}> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
     else:

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Refresh the YOLO-World backend's evidence only (subset of tools/collect_profiles.sh):  gpurun -- 'bash tools/collect_yolo_profiles.sh r02'
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+PY="python $ROOT/bench.py"
+$PY --heuristic yolo --steps 8 --warmup 1 > "$OUT/${TAG}_bench_yolo.json" 2>> "$OUT/bench_yolo.err"
+rm -rf /tmp/prof_yolo
+rocprofv3 --kernel-trace --stats -d /tmp/prof_yolo -o kt -- $PY --heuristic yolo --steps 8 --warmup 1 --no-cpu-baseline --no-verify > "$OUT/${TAG}_bench_yolo_under_rocprofv3.json" 2> "$OUT/rocprof_yolo.err"
+DBY=$(find /tmp/prof_yolo -name '*.db' | head -1)
+WINY=$(python -c "import json; d=json.load(open('$OUT/${TAG}_bench_yolo_under_rocprofv3.json')); print(d['ms_per_step'] * d['steps'])")
+python $ROOT/tools/rocpd_stats.py "$DBY" --window-ms "$WINY" > "$OUT/${TAG}_yolo_rocprofv3_kernel_stats_timed_region.md"
+rm -rf /tmp/prof_yolo2
+rocprofv3 --kernel-trace -d /tmp/prof_yolo2 -o kt -- python $ROOT/tools/yolo_forward_probe.py 32 > "$OUT/${TAG}_yolo_forward_probe.log" 2>&1
+python $ROOT/tools/rocpd_shapes.py "$(find /tmp/prof_yolo2 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_kernel_shapes_b32.md"
+rm -rf /tmp/prof_yolo3
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d /tmp/prof_yolo3 -o pmc -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2> "$OUT/rocprof_yolo_pmc.err"
+python $ROOT/tools/rocpd_pmc.py "$(find /tmp/prof_yolo3 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_pmc_valu_by_kernel.md"
+rm -rf /tmp/prof_yolo4
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_yolo4 -o pmc -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2>> "$OUT/rocprof_yolo_pmc.err"
+rm -rf /tmp/prof_yolo5
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_yolo5 -o pmc -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2>> "$OUT/rocprof_yolo_pmc.err"
+python $ROOT/tools/rocpd_traffic.py "$(find /tmp/prof_yolo4 -name '*.db' | head -1)" "$(find /tmp/prof_yolo5 -name '*.db' | head -1)" conv_valu > "$OUT/${TAG}_yolo_pmc_conv_traffic.json"
+ls -la "$OUT" | grep yolo
