@@ -70,6 +70,34 @@ def test_detector_vs_oracle(yolo, H, W, rows, cols, B):
             assert mask[cell] == want
 
 
+@pytest.mark.parametrize("scale", ["s", "m", "x"])
+def test_other_model_scales(scale):
+    """The layer program is data: YOLO-World-v2-S / M / X (other widths, depths, head counts -- X is what the reference's
+    hard-coded config names) run through the same kernels; dense scores vs the CPU statement, selection teacher-forced."""
+    from oracle import yolo_ref as R
+    from tstar_amd import yolo_world as Y
+    from tstar_amd.yolo import YoloDetector
+    sd = Y.synthetic_state_dict(2, scale)
+    det = YoloDetector(sd, scale, max_batch=1)
+    rs = np.random.RandomState(7)
+    txt = rs.standard_normal((5, 512)).astype(np.float32)
+    txt /= np.linalg.norm(txt, axis=1, keepdims=True)
+    det.set_text_feats(txt, [1.0, 1.0, 0.5, 0.5, 0.5])
+    img = GU.detector_test_image(80, 285, 600)
+    r = det.detect(torch.from_numpy(img).cuda().unsqueeze(0), 1, 1, want_dense=True)
+    torch.cuda.synchronize()
+    ref = R.detect(sd, [img], txt)[0]
+    dsc, dbx = r.dense_scores[0].cpu().numpy(), r.dense_boxes[0].cpu().numpy()
+    err = np.abs(dsc - ref["dense_scores"]).max()
+    assert err < 1e-4, err
+    assert np.abs(dbx - ref["dense_boxes"]).max() < 0.05
+    sel = R.select(dsc, dbx, (285, 600))
+    n = int(r.n_kept[0])
+    assert n == len(sel["scores"]) and np.array_equal(r.scores[0, :n].cpu().numpy(), sel["scores"])
+    assert np.array_equal(r.labels[0, :n].cpu().numpy(), sel["labels"]) and np.array_equal(r.boxes[0, :n].cpu().numpy(), sel["xyxy"])
+    det.close()
+
+
 def test_letterbox_input_is_byte_exact(yolo):
     """The ingest (keep-ratio AREA / LINEAR resize, pad 114, channel swap, / 255) feeds the first conv; it is integer work
     and must agree with the oracle exactly -- checked through a 1-query detector whose stem sees only that input: here via

@@ -792,7 +792,7 @@ int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, cons
     auto fail = [&](int rc) { tstar_yolo_destroy(h); return rc; };
     for (int i = 0; i < n_bufs; ++i) {
         const int H = h_bufs[i * 3], W = h_bufs[i * 3 + 1], Cc = h_bufs[i * 3 + 2];
-        if (H < 1 || W < 1 || Cc < 1 || (Cc % 4 && i != input_buf)) { set_error("tstar_yolo_create: bad buffer shape"); return fail(TSTAR_ERR_ARG); }
+        if (H < 1 || W < 1 || Cc < 1) { set_error("tstar_yolo_create: bad buffer shape"); return fail(TSTAR_ERR_ARG); }
         h->buf_h.push_back(H); h->buf_w.push_back(W); h->buf_c.push_back(Cc);
     }
     if (h->buf_h[input_buf] != YOLO_IMG || h->buf_w[input_buf] != YOLO_IMG || h->buf_c[input_buf] != 3) {
@@ -806,7 +806,7 @@ int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, cons
         bool ok = true;
         if (w[0] == OP_CONV) {
             ok = buf_ok(w[1]) && buf_ok(w[4]) && w[3] >= 1 && w[6] >= 1 && (w[7] == 1 || w[7] == 3) && (w[8] == 1 || w[8] == 2) &&
-                 w[2] >= 0 && w[2] + w[3] <= h->buf_c[w[1]] && w[5] >= 0 && w[5] + w[6] <= h->buf_c[w[4]] &&
+                 w[2] >= 0 && w[2] + w[3] <= h->buf_c[w[1]] && w[5] >= 0 && w[5] + w[6] <= h->buf_c[w[4]] && h->buf_c[w[4]] % 4 == 0 &&
                  off_ok(w[10], (long long)w[6] * w[7] * w[7] * w[3]) && (w[11] < 0 || off_ok(w[11], w[6])) &&
                  (w[12] == MODE_PLAIN || (buf_ok(w[13]) && w[14] >= 0));
             if (ok) {
@@ -814,9 +814,11 @@ int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, cons
                 ok = Ho == h->buf_h[w[4]] && Wo == h->buf_w[w[4]];
             }
         } else if (w[0] == OP_POOL5) {
-            ok = buf_ok(w[1]) && w[4] == w[1] && w[3] % 4 == 0 && w[2] + w[3] <= h->buf_c[w[1]] && w[5] + w[3] <= h->buf_c[w[1]];
+            ok = buf_ok(w[1]) && w[4] == w[1] && w[3] % 4 == 0 && w[2] % 4 == 0 && w[5] % 4 == 0 && h->buf_c[w[1]] % 4 == 0 &&
+                 w[2] + w[3] <= h->buf_c[w[1]] && w[5] + w[3] <= h->buf_c[w[1]];
         } else if (w[0] == OP_UPCOPY) {
-            ok = buf_ok(w[1]) && buf_ok(w[4]) && (w[6] == 1 || w[6] == 2) && w[3] % 4 == 0 && w[2] + w[3] <= h->buf_c[w[1]] &&
+            ok = buf_ok(w[1]) && buf_ok(w[4]) && (w[6] == 1 || w[6] == 2) && w[3] % 4 == 0 && w[2] % 4 == 0 && w[5] % 4 == 0 &&
+                 h->buf_c[w[1]] % 4 == 0 && h->buf_c[w[4]] % 4 == 0 && w[2] + w[3] <= h->buf_c[w[1]] &&
                  w[5] + w[3] <= h->buf_c[w[4]] && h->buf_h[w[1]] * w[6] == h->buf_h[w[4]] && h->buf_w[w[1]] * w[6] == h->buf_w[w[4]];
         } else if (w[0] == OP_ATTN) {
             ok = buf_ok(w[1]) && buf_ok(w[4]) && w[7] >= 0 && w[7] < n_guides && w[6] >= 1 && w[3] % w[6] == 0 && h->buf_c[w[4]] == w[6] &&
