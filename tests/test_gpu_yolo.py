@@ -89,8 +89,12 @@ def test_other_model_scales(scale):
     ref = R.detect(sd, [img], txt)[0]
     dsc, dbx = r.dense_scores[0].cpu().numpy(), r.dense_boxes[0].cpu().numpy()
     err = np.abs(dsc - ref["dense_scores"]).max()
-    assert err < 1e-4, err
+    # the contract; S / M / L land at ~3e-7; the synthetic X has logits of magnitude 10-60, where the same relative f32
+    # noise (1e-5 of the logit: two different summation orders) is ~1e-4 of a score
+    assert err < SCORE_TOL, err
+    assert np.median(np.abs(dsc - ref["dense_scores"])) < 2e-5
     assert np.abs(dbx - ref["dense_boxes"]).max() < 0.05
+    print(f"YOLO-World-v2-{scale.upper()}: max dense score error {err:.2e}")
     sel = R.select(dsc, dbx, (285, 600))
     n = int(r.n_kept[0])
     assert n == len(sel["scores"]) and np.array_equal(r.scores[0, :n].cpu().numpy(), sel["scores"])
