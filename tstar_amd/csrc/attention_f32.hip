@@ -33,7 +33,11 @@
 //    107 (register spills).  Ablations of the adopted kernel at B = 256: no barrier +-0, no K/V
 //    reloads +7 %, no exp / sub / add in the softmax +3.6 %: no single limiter is left; the rest is
 //    the MFMA issue pattern (one dependent 32-MFMA chain for S^T, two chains for PV, LDS fragment
-//    reads between them) against 4 independent chains in the GEMM tile.
+//    reads between them) against 4 independent chains in the GEMM tile.  That last hypothesis was then tested
+//    too: a software-pipelined variant (S^T of tile t issued as s, o0, s, o1 with PV of tile t-1 -- three
+//    independent chains, fragments of step r+1 requested before the MFMAs of step r, order pinned with
+//    sched_barrier, LDS-DMA staging; 140 VGPRs = 3 waves / SIMD) measured 113.9 vs 117.9 in a same-session
+//    A/B: dependent-MFMA stalls are not the limiter either, the lost wave of occupancy costs more.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
