@@ -14,7 +14,11 @@
 //                        workgroup, 8 x 4 outputs per lane, K = (ky, kx, ci) staged through LDS in slices of 16 with
 //                        ds_read_b128 fragment reads; fused bias / SiLU / residual / attention-gate epilogue; reads and
 //                        writes at channel offsets so torch.cat never copies.  Bound: f32 VALU issue (157.3 TFLOP/s
-//                        spec; a tiled f32 VALU GEMM sustains about a third of it on this part).
+//                        spec; tools/lab/pkfma_rate.hip measures 140 for a pure v_pk_fma_f32 stream at 8 waves / SIMD and
+//                        108 at the 2 waves / SIMD a 128-accumulator tile leaves) shared with the LDS pipe.
+//   conv_sw_kernel       the same convolution with the weights as SCALAR operands (s_load_dwordx16 rows of the transposed
+//                        matrix feeding v_pk_fma_f32 from SGPRs): a quarter of the LDS traffic per FMA; used for the
+//                        layers with >= 400 workgroups of 512 pixels x 64 channels (see the kernel's comment).
 //   pool5 / upcopy / attn / letterbox / head_decode  HBM-bound elementwise & small reductions (wave shuffles).
 //   sort_nms_kernel      per image: bitonic sort of the (score, anchor, class) candidates, class-aware greedy NMS run by
 //                        ONE wavefront (kept boxes in LDS, lanes test them in parallel, __ballot decides), top-k.
@@ -44,7 +48,9 @@ struct ConvArgs {
     const float* src; int src_ld, src_off, cin, H, W;       // input NHWC [B,H,W,src_ld], channels [src_off, src_off+cin)
     float* dst; int dst_ld, dst_off, cout, Ho, Wo;
     const float* w;                                          // [cout][ks*ks*cin]
+    const float* wt;                                         // the same matrix transposed, [ks*ks*cin][cout] (scalar-weight kernel)
     const float* bias;                                       // [cout] or null
+    unsigned zoff;                                           // element offset (from src) of the zero quad kept behind the source buffer
     const float* aux; int aux_ld, aux_off;                   // residual tensor (same spatial size as dst) or attention [P, heads]
     int ks, stride, act, mode, heads;
     int M;                                                   // B * Ho * Wo
@@ -61,12 +67,14 @@ __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v));
 constexpr int CBM = 128, CBK = 16, CLD_A = CBM + 4;
 
 template <int KS, int TN>
-__global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int nt) {
     constexpr int BN = 16 * TN, CLD_W = BN + 4, NWQ = BN / 64;       // NWQ weight float4 per thread per slice
     __shared__ __attribute__((aligned(16))) float As[CBK][CLD_A];
     __shared__ __attribute__((aligned(16))) float Ws[CBK][CLD_W];
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.x * CBM, n0 = blockIdx.y * BN;
+    // 1-D grid, XCD-aware: an XCD gets a contiguous run of tiles, the channel tiles of one pixel tile adjacent (shared L2)
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * CBM, n0 = (tile % nt) * BN;
     // staging roles: A tile 128 x 16 = 512 float4 -> 2 per thread (rows tid/4 and tid/4 + 64, k quad tid%4);
     //                W tile  BN x 16 -> NWQ per thread (rows tid/4 (+64))
     const int kq = (tid & 3) * 4;
@@ -194,6 +202,174 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ scalar-weight conv on the VALU
+// The tile kernel above needs 16 LDS floats (8 pixels + 8 weights) per 64 FMAs and a lane; with the CU's four SIMDs on
+// one LDS pipe that is as many LDS cycles as packed-FMA cycles, and neither pipe gets past half rate.  Here the weights
+// never touch LDS or VGPRs: every lane of a wave works on the SAME 16 output channels, so the weight row of a k is
+// wave-uniform -- one s_load_dwordx16 from the transposed matrix [K][cout] into SGPRs -- and feeds v_pk_fma_f32 as its
+// scalar operand (channel pairs are the packed halves, the pixel value is broadcast with op_sel).  A lane owns 8 pixels
+// x 16 channels (128 accumulators); the four waves of a workgroup share one 512-pixel x 16-k activation tile in LDS
+// (pixel-major rows of 16 + 4 floats: the staging ds_write_b128 needs no transposition, the ds_read_b128 of 64 lanes at
+// an 80-byte stride are conflict-free) and take one 16-channel group each.  Per k and wave: 2 ds_read_b128 + 1 s_load
+// for 64 v_pk_fma_f32, a quarter of the LDS traffic per FMA of the tile kernel.  The accumulation order over k is the
+// same sequential (ky, kx, ci) fmaf chain, so both kernels give bit-identical outputs.
+constexpr int SWM = 512, SWK = 16, SWLD = SWK + 4, SWN = 64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// acc.xy += a.x * w.xy  /  acc.xy += a.y * w.xy   (w in an SGPR pair)
+__device__ __forceinline__ void pkfma_lo(f32x2& acc, f32x2 av, f32x2 w) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(av), "s"(w)); }
+__device__ __forceinline__ void pkfma_hi(f32x2& acc, f32x2 av, f32x2 w) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(av), "s"(w)); }
+
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_sw_kernel(ConvArgs a, int mt, int nt) {
+    __shared__ __attribute__((aligned(16))) float As[SWM][SWLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 1-D grid, XCD-aware: each XCD gets a contiguous run of tiles, channel blocks of one pixel tile adjacent, so the nt
+    // workgroups that read the same activation tile (and their 3x3 neighbours) share one L2
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * SWM;
+    const int cg0 = (tile % nt) * SWN + wave * 16;                   // wave-uniform channel group
+    const bool active = cg0 < a.cout;                                // cout % 16 == 0 (launcher)
+    // staging roles: thread -> pixels (tid / 4) + 64 i, k quad tid % 4.  Per pixel: the element offset of its top-left
+    // tap and one validity bit per tap (padding and the M tail), so a slice costs a bit test, a select and an add per load;
+    // a padded tap reads the zero quad kept behind every activation buffer (zoff) and needs no fix-up afterwards
+    const int kq4 = (tid & 3) * 4, sr0 = tid >> 2;
+    unsigned poff[8], pval[8];
+    {
+        const int hw = a.Ho * a.Wo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + sr0 + 64 * i;
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const int y0 = oy * a.stride - (KS >> 1), x0 = ox * a.stride - (KS >> 1);
+            poff[i] = (unsigned)(((b * a.H + y0) * a.W + x0) * a.src_ld + a.src_off + kq4);   // wraps for y0/x0 = -1; only used with a valid tap
+            unsigned v = 0;
+#pragma unroll
+            for (int t = 0; t < KS * KS; ++t) {
+                const int iy = y0 + t / KS, ix = x0 + t % KS;
+                v |= (unsigned)(ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) << t;
+            }
+            pval[i] = v;
+        }
+    }
+    const int K = KS * KS * a.cin;
+    f32x4 ra[8];
+    auto load_tile = [&](int k0) {
+        // k0 is a multiple of 16 and cin % 16 == 0: a slice stays inside one (ky, kx) tap
+        const int tap = k0 / a.cin, ci = k0 - tap * a.cin;
+        const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
+        const unsigned toff = (unsigned)((ky * a.W + kx) * a.src_ld + ci), tbit = 1u << tap;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.src + ((pval[i] & tbit) ? poff[i] + toff : a.zoff));
+    };
+    f32x2 acc[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] = f32x2{0.f, 0.f};
+    // address space 4 (constant): the weight rows are wave-uniform and never written by this kernel -> s_load_dwordx16
+    typedef __attribute__((address_space(4))) const f32x16 cw16;
+    const float* wcol = a.wt + (active ? cg0 : 0);
+
+    load_tile(0);
+    for (int k0 = 0; k0 < K; k0 += SWK) {
+        // weight rows of the first two k of the slice: in flight across the barriers
+        f32x16 wna = *(const cw16*)(unsigned long long)(wcol + (size_t)k0 * a.cout);
+        f32x16 wnb = *(const cw16*)(unsigned long long)(wcol + (size_t)(k0 + 1) * a.cout);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&As[sr0 + 64 * i][kq4]) = ra[i];
+        __syncthreads();
+        if (k0 + SWK < K) load_tile(k0 + SWK);                     // global loads of the next slice fly during the FMAs
+        if (active) {
+            f32x4 av[8], an[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(&As[lane + 64 * j][0]);
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {                     // two k per batch of scalar loads
+                    // SMEM returns out of order, so every wait on it is lgkmcnt(0): the wait for this batch is placed HERE,
+                    // before the next batch is issued, and each batch then has two k (128 v_pk_fma_f32) to arrive
+                    asm volatile("" :: "s"(wna[0]), "s"(wnb[0]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x16 wa = wna, wb = wnb;
+                    const int kn = kq * 4 + kp * 2 + 2;              // compile-time
+                    if (kn < SWK) {
+                        wna = *(const cw16*)(unsigned long long)(wcol + (size_t)(k0 + kn) * a.cout);
+                        wnb = *(const cw16*)(unsigned long long)(wcol + (size_t)(k0 + kn + 1) * a.cout);
+                    }
+                    if (kp == 0 && kq < 3) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) an[j] = *reinterpret_cast<const f32x4*>(&As[lane + 64 * j][kq * 4 + 4]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x2 w2 = {wa[2 * c], wa[2 * c + 1]};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pkfma_lo(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x2 w2 = {wb[2 * c], wb[2 * c + 1]};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pkfma_hi(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kq < 3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = an[j];
+                }
+            }
+        }
+    }
+    if (!active) return;
+    // epilogue: as in the tile kernel; a lane writes 16 consecutive channels of each of its 8 pixels
+    const int ch_per_head = a.mode == MODE_ATTN_MUL ? a.cout / a.heads : 1;
+    float bias[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) bias[c] = a.bias ? a.bias[cg0 + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = m0 + lane + 64 * j;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[j][2 * q + (e >> 1)][e & 1] + bias[4 * q + e];
+                if (a.act == YACT_SILU) t = silu(t);
+                v[e] = t;
+            }
+            const int nb = cg0 + 4 * q;
+            if (a.mode == MODE_RESIDUAL) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(a.aux + (size_t)m * a.aux_ld + a.aux_off + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r[e];
+            } else if (a.mode == MODE_ATTN_MUL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= a.aux[(size_t)m * a.aux_ld + a.aux_off + (nb + e) / ch_per_head];
+            }
+            *reinterpret_cast<f32x4*>(a.dst + (size_t)m * a.dst_ld + a.dst_off + nb) = v;
+        }
+    }
+}
+
+// W [cout][K] -> Wt [K][cout], once per model at tstar_yolo_create
+__global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int K) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)cout * K) return;
+    const int n = (int)(i % cout), k = (int)(i / cout);
+    wt[i] = w[(size_t)n * K + k];
+}
+
 // direct form for small K = ks*ks*cin (the 3-channel stem: K = 27): the whole weight matrix sits in LDS as [K][cout];
 // a lane computes 4 neighbouring pixels x 16 output channels, so every weight quad read from LDS feeds 16 FMAs and the
 // 64-channel output row of a pixel is written as 16-byte stores.  HBM-bound by its output (64 channels x 4 B per pixel).
@@ -266,15 +442,31 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     TSTAR_REQUIRE(a.cout % 4 == 0 && a.dst_ld % 4 == 0 && a.dst_off % 4 == 0, "yolo conv: output channels must be 16-byte aligned");
     const bool tiled = a.cin % CBK == 0 && a.src_ld % 4 == 0 && a.src_off % 4 == 0 && (a.ks == 1 || a.ks == 3);
-    if (tiled) {
+    // scalar-weight form: 512-pixel x 64-channel workgroups; taken from 400 workgroups up (measured on the L model at B = 32:
+    // thresholds 200 / 300 / 400 / 800 give 74.3 / 73.4 / 73.3 / 77.0 ms per batch, the tile kernel alone 80.6) -- below that
+    // the smaller tiles of the tile kernel spread the layer over more CUs
+    static const int sw_env = [] { const char* e = getenv("TSTAR_YOLO_SW"); return e ? atoi(e) : -1; }();
+    const long long sw_blocks = (long long)cdiv(a.M, SWM) * cdiv(a.cout, SWN);
+    const bool sw_ok = tiled && a.wt && a.cout % 16 == 0 && a.zoff != 0 && a.zoff < (1u << 30);   // byte offsets fit 32 bits
+    static const int sw_min = [] { const char* e = getenv("TSTAR_YOLO_SW_MIN"); return e ? atoi(e) : 400; }();
+    if (sw_ok && (sw_env < 0 ? sw_blocks >= sw_min : sw_env > 0)) {
+        const int mt = cdiv(a.M, SWM), nt = cdiv(a.cout, SWN);
+        const dim3 grid(mt * nt);
+        const bool prof = prof_enabled();
+        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
+        if (a.ks == 1) hipLaunchKernelGGL((conv_sw_kernel<1>), grid, dim3(256), 0, s, a, mt, nt);
+        else hipLaunchKernelGGL((conv_sw_kernel<3>), grid, dim3(256), 0, s, a, mt, nt);
+        if (prof) prof_stop(PROF_CONV, s);
+    } else if (tiled) {
         // 128-channel tiles (8 x 8 outputs per lane) when the layer has the channels and enough pixels to fill the chip
         static const int tn_env = [] { const char* e = getenv("TSTAR_YOLO_TN"); return e ? atoi(e) : 0; }();
         const bool wide = tn_env ? tn_env == 8 : (a.cout % 128 == 0 && (long long)cdiv(a.M, CBM) * (a.cout / 128) >= 512);
-        const dim3 grid(cdiv(a.M, CBM), cdiv(a.cout, wide ? 128 : 64));
+        const int mt = cdiv(a.M, CBM), nt = cdiv(a.cout, wide ? 128 : 64);
+        const dim3 grid(mt * nt);
         const bool prof = prof_enabled();
         if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
-        if (a.ks == 1) { if (wide) hipLaunchKernelGGL((conv_valu_kernel<1, 8>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_valu_kernel<1, 4>), grid, dim3(256), 0, s, a); }
-        else { if (wide) hipLaunchKernelGGL((conv_valu_kernel<3, 8>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_valu_kernel<3, 4>), grid, dim3(256), 0, s, a); }
+        if (a.ks == 1) { if (wide) hipLaunchKernelGGL((conv_valu_kernel<1, 8>), grid, dim3(256), 0, s, a, mt, nt); else hipLaunchKernelGGL((conv_valu_kernel<1, 4>), grid, dim3(256), 0, s, a, mt, nt); }
+        else { if (wide) hipLaunchKernelGGL((conv_valu_kernel<3, 8>), grid, dim3(256), 0, s, a, mt, nt); else hipLaunchKernelGGL((conv_valu_kernel<3, 4>), grid, dim3(256), 0, s, a, mt, nt); }
         if (prof) prof_stop(PROF_CONV, s);
     } else {
         TSTAR_REQUIRE(a.mode == MODE_PLAIN, "yolo conv: the direct form has no fused residual / gate");
@@ -741,6 +933,7 @@ struct YoloLevel { int e_buf, r_buf, size, stride, param_off; float logit_scale,
 
 struct tstar_yolo {
     float* d_blob = nullptr; size_t n_blob = 0;
+    float* d_blob_t = nullptr;                                // conv matrices transposed to [K][cout], at the same offsets
     std::vector<float> h_small;                               // host copy of the per-level scalars
     std::vector<YoloOp> ops;
     std::vector<int> buf_h, buf_w, buf_c;
@@ -766,7 +959,7 @@ extern "C" {
 
 int tstar_yolo_destroy(tstar_yolo* h) {
     if (!h) return TSTAR_OK;
-    void* ptrs[] = {h->d_blob, h->d_text, h->d_textn, h->d_qweight, h->d_setQ, h->d_image_set, h->d_iota, h->d_cand_count,
+    void* ptrs[] = {h->d_blob, h->d_blob_t, h->d_text, h->d_textn, h->d_qweight, h->d_setQ, h->d_image_set, h->d_iota, h->d_cand_count,
                     h->d_tmp_u8, h->d_boxes, h->d_cand};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (float* p : h->bufs) if (p) (void)hipFree(p);
@@ -829,6 +1022,16 @@ int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, cons
     }
     hipError_t e = hipMalloc(&h->d_blob, n_blob * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->d_blob, h_blob, n_blob * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&h->d_blob_t, n_blob * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->d_blob_t, 0, n_blob * sizeof(float));
+    for (size_t i = 0; i < h->ops.size() && e == hipSuccess; ++i) {
+        const int* w = h->ops[i].w;
+        if (w[0] != OP_CONV) continue;
+        const int cout = w[6], K = w[7] * w[7] * w[3];
+        hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(cout * K, 256)), dim3(256), 0, 0, h->d_blob + w[10], h->d_blob_t + w[10], cout, K);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     for (int i = 0; i < n_guides && e == hipSuccess; ++i) {
         YoloGuide g{h_guides[i * 5], h_guides[i * 5 + 1], h_guides[i * 5 + 2], h_guides[i * 5 + 3], h_guides[i * 5 + 4], nullptr};
         if (g.embed < 1 || g.heads < 1 || g.embed % g.heads || !off_ok(g.w_off, (long long)g.embed * YOLO_TEXT) || !off_ok(g.b_off, g.embed) ||
@@ -851,7 +1054,8 @@ int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, cons
     for (int i = 0; i < n_bufs && e == hipSuccess; ++i) {
         float* p = nullptr;
         const size_t n = (size_t)max_batch * h->buf_h[i] * h->buf_w[i] * h->buf_c[i];
-        e = hipMalloc(&p, n * sizeof(float));
+        e = hipMalloc(&p, (n + 4) * sizeof(float));                  // + the zero quad padded conv taps read (conv_sw_kernel)
+        if (e == hipSuccess) e = hipMemset(p + n, 0, 4 * sizeof(float));
         h->bufs.push_back(p);
     }
     const size_t nsq = (size_t)YOLO_SETS * YOLO_MAX_Q;
@@ -915,10 +1119,12 @@ static int run_program(tstar_yolo* h, int B, const int* d_image_set, hipStream_t
             ConvArgs a{};
             a.src = h->bufs[w[1]]; a.src_ld = h->buf_c[w[1]]; a.src_off = w[2]; a.cin = w[3]; a.H = h->buf_h[w[1]]; a.W = h->buf_w[w[1]];
             a.dst = h->bufs[w[4]]; a.dst_ld = h->buf_c[w[4]]; a.dst_off = w[5]; a.cout = w[6]; a.Ho = h->buf_h[w[4]]; a.Wo = h->buf_w[w[4]];
-            a.ks = w[7]; a.stride = w[8]; a.act = w[9]; a.w = h->d_blob + w[10]; a.bias = w[11] >= 0 ? h->d_blob + w[11] : nullptr;
+            a.ks = w[7]; a.stride = w[8]; a.act = w[9]; a.w = h->d_blob + w[10]; a.wt = h->d_blob_t + w[10]; a.bias = w[11] >= 0 ? h->d_blob + w[11] : nullptr;
             a.mode = w[12];
             if (a.mode != MODE_PLAIN) { a.aux = h->bufs[w[13]]; a.aux_ld = h->buf_c[w[13]]; a.aux_off = w[14]; a.heads = h->buf_c[w[13]]; }
             a.M = B * a.Ho * a.Wo;
+            const size_t zo = (size_t)h->max_batch * a.H * a.W * a.src_ld;
+            a.zoff = zo < (1ull << 30) ? (unsigned)zo : 0;
             RC(launch_conv(a, s));
         } else if (w[0] == OP_POOL5) {
             const int H = h->buf_h[w[1]], W = h->buf_w[w[1]];
