@@ -51,7 +51,9 @@ python $ROOT/tools/rocpd_gaps.py "$DB" --window-ms "$WIN" > "$OUT/${TAG}_gpu_idl
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES"; do
     N=$(echo $C | tr ' ' '_')
     rm -rf /tmp/prof_$N
-    rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 4 --warmup 0 --no-cpu-baseline > /dev/null 2> "$OUT/rocprof_$N.err"
+    # --no-grid4 --no-verify: every GEMM dispatch of the run is one of the timed steps' (plus the text tower's 48 tiny ones),
+    # so the per-launch averages are over the same population as the bench line's avg_launch_gflop
+    rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify > /dev/null 2> "$OUT/rocprof_$N.err"
 done
 F=$(find /tmp/prof_FETCH_SIZE -name '*.db' | head -1)
 W=$(find /tmp/prof_WRITE_SIZE -name '*.db' | head -1)
@@ -67,6 +69,10 @@ cp "$OUT/${TAG}_pmc_gemm_traffic.json" "$ROOT/profiles/${TAG}_pmc_gemm_traffic.j
 $PY > "$OUT/${TAG}_bench.json" 2>> "$OUT/bench.err"
 
 # 5. kernel microbenchmarks
+rm -rf /tmp/prof_sf
+rocprofv3 --kernel-trace -d /tmp/prof_sf -o sf -- python $ROOT/tools/small_forward_probe.py 40 > "$OUT/${TAG}_small_forward_probe.log" 2>&1
+python $ROOT/tools/rocpd_gaps.py "$(find /tmp/prof_sf -name '*.db' | head -1)" 0.9 > "$OUT/${TAG}_small_forward_idle_gaps.txt"
+[ -x $ROOT/tools/lab/pkfma_rate ] && $ROOT/tools/lab/pkfma_rate > "$OUT/${TAG}_valu_pkfma_rate.log" 2>&1
 python $ROOT/tools/bench_gemm_cfg.py > "$OUT/${TAG}_gemm_tile_configs.log" 2>&1
 python $ROOT/tools/sweep_small_m.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_gemm_subwave_sweep.log"
 python $ROOT/tools/bench_kernels.py > "$OUT/${TAG}_kernel_microbench.log" 2>&1

@@ -207,21 +207,23 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 // one LDS pipe that is as many LDS cycles as packed-FMA cycles, and neither pipe gets past half rate.  Here the weights
 // never touch LDS or VGPRs: every lane of a wave works on the SAME 16 output channels, so the weight row of a k is
 // wave-uniform -- one s_load_dwordx16 from the transposed matrix [K][cout] into SGPRs -- and feeds v_pk_fma_f32 as its
-// scalar operand (channel pairs are the packed halves, the pixel value is broadcast with op_sel).  A lane owns 8 pixels
-// x 16 channels (128 accumulators); the four waves of a workgroup share one 512-pixel x 16-k activation tile in LDS
+// scalar operand (channel pairs are the packed halves, the pixel value is broadcast with op_sel).  A lane owns P = 8 (or
+// 4) pixels x 16 channels (128 / 64 accumulators: 2 / 4 waves per SIMD); the four waves of a workgroup share one 64 P-pixel
+// x 16-k activation tile in LDS
 // (pixel-major rows of 16 + 4 floats: the staging ds_write_b128 needs no transposition, the ds_read_b128 of 64 lanes at
 // an 80-byte stride are conflict-free) and take one 16-channel group each.  Per k and wave: 2 ds_read_b128 + 1 s_load
 // for 64 v_pk_fma_f32, a quarter of the LDS traffic per FMA of the tile kernel.  The accumulation order over k is the
 // same sequential (ky, kx, ci) fmaf chain, so both kernels give bit-identical outputs.
-constexpr int SWM = 512, SWK = 16, SWLD = SWK + 4, SWN = 64;
+constexpr int SWK = 16, SWLD = SWK + 4, SWN = 64;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // acc.xy += a.x * w.xy  /  acc.xy += a.y * w.xy   (w in an SGPR pair)
 __device__ __forceinline__ void pkfma_lo(f32x2& acc, f32x2 av, f32x2 w) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(av), "s"(w)); }
 __device__ __forceinline__ void pkfma_hi(f32x2& acc, f32x2 av, f32x2 w) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(av), "s"(w)); }
 
-template <int KS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_sw_kernel(ConvArgs a, int mt, int nt) {
+template <int KS, int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 : 4, P == 8 ? 2 : 4))) void conv_sw_kernel(ConvArgs a, int mt, int nt) {
+    constexpr int SWM = 64 * P;                                     // pixels per workgroup: P per lane
     __shared__ __attribute__((aligned(16))) float As[SWM][SWLD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,11 +237,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // tap and one validity bit per tap (padding and the M tail), so a slice costs a bit test, a select and an add per load;
     // a padded tap reads the zero quad kept behind every activation buffer (zoff) and needs no fix-up afterwards
     const int kq4 = (tid & 3) * 4, sr0 = tid >> 2;
-    unsigned poff[8], pval[8];
+    unsigned poff[P], pval[P];
     {
         const int hw = a.Ho * a.Wo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < P; ++i) {
             const int m = m0 + sr0 + 64 * i;
             const bool ok = m < a.M;
             const int mm = ok ? m : 0;
@@ -257,18 +259,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     const int K = KS * KS * a.cin;
-    f32x4 ra[8];
+    f32x4 ra[P];
     auto load_tile = [&](int k0) {
         // k0 is a multiple of 16 and cin % 16 == 0: a slice stays inside one (ky, kx) tap
         const int tap = k0 / a.cin, ci = k0 - tap * a.cin;
         const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
         const unsigned toff = (unsigned)((ky * a.W + kx) * a.src_ld + ci), tbit = 1u << tap;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.src + ((pval[i] & tbit) ? poff[i] + toff : a.zoff));
+        for (int i = 0; i < P; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.src + ((pval[i] & tbit) ? poff[i] + toff : a.zoff));
     };
-    f32x2 acc[8][8];
+    f32x2 acc[P][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < P; ++j)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[j][c] = f32x2{0.f, 0.f};
     // address space 4 (constant): the weight rows are wave-uniform and never written by this kernel -> s_load_dwordx16
@@ -282,13 +284,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         f32x16 wnb = *(const cw16*)(unsigned long long)(wcol + (size_t)(k0 + 1) * a.cout);
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&As[sr0 + 64 * i][kq4]) = ra[i];
+        for (int i = 0; i < P; ++i) *reinterpret_cast<f32x4*>(&As[sr0 + 64 * i][kq4]) = ra[i];
         __syncthreads();
         if (k0 + SWK < K) load_tile(k0 + SWK);                     // global loads of the next slice fly during the FMAs
         if (active) {
-            f32x4 av[8], an[8];
+            f32x4 av[P], an[P];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(&As[lane + 64 * j][0]);
+            for (int j = 0; j < P; ++j) av[j] = *reinterpret_cast<const f32x4*>(&As[lane + 64 * j][0]);
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
 #pragma unroll
@@ -305,26 +307,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     if (kp == 0 && kq < 3) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) an[j] = *reinterpret_cast<const f32x4*>(&As[lane + 64 * j][kq * 4 + 4]);
+                        for (int j = 0; j < P; ++j) an[j] = *reinterpret_cast<const f32x4*>(&As[lane + 64 * j][kq * 4 + 4]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const f32x2 w2 = {wa[2 * c], wa[2 * c + 1]};
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) pkfma_lo(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
+                        for (int j = 0; j < P; ++j) pkfma_lo(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
                     }
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const f32x2 w2 = {wb[2 * c], wb[2 * c + 1]};
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) pkfma_hi(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
+                        for (int j = 0; j < P; ++j) pkfma_hi(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (kq < 3) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) av[j] = an[j];
+                    for (int j = 0; j < P; ++j) av[j] = an[j];
                 }
             }
         }
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int c = 0; c < 16; ++c) bias[c] = a.bias ? a.bias[cg0 + c] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < P; ++j) {
         const int m = m0 + lane + 64 * j;
         if (m >= a.M) continue;
 #pragma unroll
@@ -442,20 +444,28 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     TSTAR_REQUIRE(a.cout % 4 == 0 && a.dst_ld % 4 == 0 && a.dst_off % 4 == 0, "yolo conv: output channels must be 16-byte aligned");
     const bool tiled = a.cin % CBK == 0 && a.src_ld % 4 == 0 && a.src_off % 4 == 0 && (a.ks == 1 || a.ks == 3);
-    // scalar-weight form: 512-pixel x 64-channel workgroups; taken from 400 workgroups up (measured on the L model at B = 32:
-    // thresholds 200 / 300 / 400 / 800 give 74.3 / 73.4 / 73.3 / 77.0 ms per batch, the tile kernel alone 80.6) -- below that
-    // the smaller tiles of the tile kernel spread the layer over more CUs
+    // scalar-weight form, chosen per layer from its size in 512-pixel x 64-channel blocks (per-layer timings of the L model
+    // at B = 32, tools/rocpd_conv_align.py -> profiles/r02_yolo_conv_kernels_by_layer.md): >= 800 blocks: 4 pixels per lane
+    // (256-pixel workgroups, 4 waves / SIMD); 400..799: 8 pixels per lane (one round of the chip's 512 two-per-CU slots);
+    // below that the 128-pixel tiles of the tile kernel spread the layer over more CUs and win by up to 2x
     static const int sw_env = [] { const char* e = getenv("TSTAR_YOLO_SW"); return e ? atoi(e) : -1; }();
-    const long long sw_blocks = (long long)cdiv(a.M, SWM) * cdiv(a.cout, SWN);
+    const long long sw_blocks = (long long)cdiv(a.M, 512) * cdiv(a.cout, SWN);
     const bool sw_ok = tiled && a.wt && a.cout % 16 == 0 && a.zoff != 0 && a.zoff < (1u << 30);   // byte offsets fit 32 bits
     static const int sw_min = [] { const char* e = getenv("TSTAR_YOLO_SW_MIN"); return e ? atoi(e) : 400; }();
+    static const int sw_p_env = [] { const char* e = getenv("TSTAR_YOLO_SW_P"); return e ? atoi(e) : 0; }();
     if (sw_ok && (sw_env < 0 ? sw_blocks >= sw_min : sw_env > 0)) {
-        const int mt = cdiv(a.M, SWM), nt = cdiv(a.cout, SWN);
+        const int sw_p = sw_p_env ? sw_p_env : (sw_blocks >= 800 ? 4 : 8);
+        const int mt = cdiv(a.M, 64 * sw_p), nt = cdiv(a.cout, SWN);
         const dim3 grid(mt * nt);
         const bool prof = prof_enabled();
         if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
-        if (a.ks == 1) hipLaunchKernelGGL((conv_sw_kernel<1>), grid, dim3(256), 0, s, a, mt, nt);
-        else hipLaunchKernelGGL((conv_sw_kernel<3>), grid, dim3(256), 0, s, a, mt, nt);
+        if (sw_p == 8) {
+            if (a.ks == 1) hipLaunchKernelGGL((conv_sw_kernel<1, 8>), grid, dim3(256), 0, s, a, mt, nt);
+            else hipLaunchKernelGGL((conv_sw_kernel<3, 8>), grid, dim3(256), 0, s, a, mt, nt);
+        } else {
+            if (a.ks == 1) hipLaunchKernelGGL((conv_sw_kernel<1, 4>), grid, dim3(256), 0, s, a, mt, nt);
+            else hipLaunchKernelGGL((conv_sw_kernel<3, 4>), grid, dim3(256), 0, s, a, mt, nt);
+        }
         if (prof) prof_stop(PROF_CONV, s);
     } else if (tiled) {
         // 128-channel tiles (8 x 8 outputs per lane) when the layer has the channels and enough pixels to fill the chip
