@@ -102,6 +102,48 @@ def test_other_model_scales(scale):
     det.close()
 
 
+def test_conv_kernels_bit_identical():
+    """The three VALU convolution kernels (LDS-tiled, scalar-weight with 8 / 4 pixels per lane) accumulate every output
+    in the same (ky, kx, ci) fmaf order: a whole forward is BIT-identical whichever kernel the per-layer policy picks.
+    The policy is read from the environment once per process, so each variant runs in its own interpreter."""
+    import os
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "yolo_conv_variant_probe.py")
+    out = {}
+    for name, env in [("tile", {"TSTAR_YOLO_SW": "0"}), ("sw8", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "8"}),
+                      ("sw4", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "4"}), ("policy", {})]:
+        e = dict(os.environ, **env)
+        for k in ("TSTAR_YOLO_SW", "TSTAR_YOLO_SW_P", "TSTAR_YOLO_SW_MIN"):
+            if k not in env:
+                e.pop(k, None)
+        p = subprocess.run([sys.executable, probe, "s", "3"], env=e, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[name] = [ln for ln in p.stdout.splitlines() if ln.startswith("SHA")][0]
+    assert len(set(out.values())) == 1, out
+
+
+def test_large_batch_default_policy_vs_oracle(yolo):
+    """B = 16 puts the 160x160 / 80x80 layers above the thresholds at which the per-layer policy switches to the
+    scalar-weight kernels (both variants): images 0 and 15 of the batch against the CPU statement, and image 0 bit-equal
+    to the same image scored alone (batch-size independence across kernels)."""
+    from oracle import yolo_ref as R
+    from tstar_amd.yolo import YoloDetector
+    det = YoloDetector(yolo["sd"], "l", max_batch=16)
+    det.set_text_feats(yolo["txt"], [1.0, 0.5, 0.5, 0.5])
+    imgs = np.stack([GU.detector_test_image(120 + b, 285, 600) for b in range(16)])
+    r = det.detect(torch.from_numpy(imgs).cuda(), 1, 1, want_dense=True)
+    r1 = det.detect(torch.from_numpy(imgs[:1]).cuda(), 1, 1, want_dense=True)
+    torch.cuda.synchronize()
+    assert torch.equal(r.dense_scores[0], r1.dense_scores[0]) and torch.equal(r.dense_boxes[0], r1.dense_boxes[0])
+    ref = R.detect(yolo["sd"], [imgs[0], imgs[15]], yolo["txt"])
+    for j, b in enumerate((0, 15)):
+        err = np.abs(r.dense_scores[b].cpu().numpy() - ref[j]["dense_scores"]).max()
+        assert err < SCORE_TOL, err
+        assert np.abs(r.dense_boxes[b].cpu().numpy() - ref[j]["dense_boxes"]).max() < 0.05
+    det.close()
+
+
 def test_letterbox_input_is_byte_exact(yolo):
     """The ingest (keep-ratio AREA / LINEAR resize, pad 114, channel swap, / 255) feeds the first conv; it is integer work
     and must agree with the oracle exactly -- checked through a 1-query detector whose stem sees only that input: here via
