@@ -482,7 +482,7 @@ def main():
     # roofline of the dominant kernel (gemm_f32_kernel): HIP events on the launch stream, this rank
     n_l, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
     _lib.check(lib.tstar_prof_read(0, C.byref(n_l), C.byref(ms), C.byref(fl)))
-    if args.heuristic == "yolo":                  # dominant kernel of the YOLO-World backend: conv_valu_kernel (category 2)
+    if args.heuristic == "yolo":                  # dominant kernels of the YOLO-World backend: the VALU convolutions (category 2)
         _lib.check(lib.tstar_prof_read(2, C.byref(n_l), C.byref(ms), C.byref(fl)))
     a_l, a_ms, a_fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
     _lib.check(lib.tstar_prof_read(1, C.byref(a_l), C.byref(a_ms), C.byref(a_fl)))
@@ -506,9 +506,9 @@ def main():
     # three bf16 MFMA products (exact activation split), priced against the dense bf16 peak.
     bound = "mfma"
     if args.heuristic == "yolo":
-        gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel (implicit-GEMM convolution, v_pk_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
+        gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel + conv_sw_kernel (implicit-GEMM convolutions, v_pk_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r02_yolo_pmc_conv_traffic.json")     # tools/collect_yolo_profiles.sh (32-image batch)
+        tp = os.path.join(ROOT, "profiles", "r02_yolo_pmc_conv_traffic.json")     # tools/collect_yolo_profiles.sh (PMC passes of this command)
         if os.path.isfile(tp):
             try:
                 traffic, traffic_src = json.load(open(tp))["bytes_per_launch_corrected"], "profiles/r02_yolo_pmc_conv_traffic.json"

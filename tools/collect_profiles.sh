@@ -22,27 +22,10 @@ $PY --steps 4 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nfram
 $PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --workload haystack --no-cpu-baseline > "$OUT/${TAG}_bench_haystack_1gpu.json" 2>> "$OUT/bench.err"
 $PY --workload haystack32 --no-cpu-baseline > "$OUT/${TAG}_bench_haystack32_1gpu.json" 2>> "$OUT/bench.err"
-$PY --heuristic yolo --steps 8 --warmup 1 > "$OUT/${TAG}_bench_yolo.json" 2>> "$OUT/bench.err"
 
-# 1b. YOLO-World backend: kernel trace of its bench command + per-shape table of one 32-image verification batch
-rm -rf /tmp/prof_yolo
-rocprofv3 --kernel-trace --stats -d /tmp/prof_yolo -o kt -- $PY --heuristic yolo --steps 8 --warmup 1 --no-cpu-baseline --no-verify > "$OUT/${TAG}_bench_yolo_under_rocprofv3.json" 2> "$OUT/rocprof_yolo.err"
-DBY=$(find /tmp/prof_yolo -name '*.db' | head -1)
-WINY=$(python -c "import json; d=json.load(open('$OUT/${TAG}_bench_yolo_under_rocprofv3.json')); print(d['ms_per_step'] * d['steps'])")
-python $ROOT/tools/rocpd_stats.py "$DBY" --window-ms "$WINY" > "$OUT/${TAG}_yolo_rocprofv3_kernel_stats_timed_region.md"
-rm -rf /tmp/prof_yolo2
-rocprofv3 --kernel-trace -d /tmp/prof_yolo2 -o kt -- python $ROOT/tools/yolo_forward_probe.py 32 > "$OUT/${TAG}_yolo_forward_probe.log" 2>&1
-python $ROOT/tools/rocpd_shapes.py "$(find /tmp/prof_yolo2 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_kernel_shapes_b32.md"
-# per-layer comparison of the three conv kernels (the launcher's policy thresholds come from this table)
-for V in "tile 0 8" "sw8 1 8" "sw4 1 4"; do
-    set -- $V
-    rm -rf /tmp/prof_yc_$1
-    TSTAR_YOLO_SW=$2 TSTAR_YOLO_SW_P=$3 rocprofv3 --kernel-trace -d /tmp/prof_yc_$1 -o kt -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2>&1
-done
-python $ROOT/tools/rocpd_conv_align.py 7 tile=$(find /tmp/prof_yc_tile -name '*.db' | head -1) sw8=$(find /tmp/prof_yc_sw8 -name '*.db' | head -1) sw4=$(find /tmp/prof_yc_sw4 -name '*.db' | head -1) > "$OUT/${TAG}_yolo_conv_kernels_by_layer.md"
-rm -rf /tmp/prof_yolo3
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d /tmp/prof_yolo3 -o pmc -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2> "$OUT/rocprof_yolo_pmc.err"
-python $ROOT/tools/rocpd_pmc.py "$(find /tmp/prof_yolo3 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_pmc_valu_by_kernel.md"
+# 1b. YOLO-World backend: its own script (bench line, kernel trace, per-shape and per-layer tables, counters)
+bash $ROOT/tools/collect_yolo_profiles.sh $TAG
+cd /tmp
 
 # 2. kernel trace of the bench command
 rm -rf /tmp/prof_kt

@@ -1,6 +1,6 @@
 """HBM-side traffic of one kernel family from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
 
-    python tools/rocpd_traffic.py <fetch.db> <write.db> <kernel substring> > profiles/rNN_pmc_traffic.json
+    python tools/rocpd_traffic.py <fetch.db> <write.db> <kernel substring[|substring...]> [command text] > profiles/rNN_pmc_traffic.json
 
 Per the MI355X guide: both counters are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a
 wide coalesced read, so it is doubled.  The counters sit on the L2's fabric side and include
@@ -15,13 +15,13 @@ def total(path, counter, sub):
     c = sqlite3.connect(path)
     n = s = 0
     for name, cn, v in c.execute("select name, counter_name, counter_value from pmc_events"):
-        if cn == counter and sub in name:
+        if cn == counter and any(x in name for x in sub.split("|")):
             n += 1
             s += v
     return n, s
 
 
-def main(fetch_db, write_db, sub):
+def main(fetch_db, write_db, sub, command=None):
     nf, f = total(fetch_db, "FETCH_SIZE", sub)
     nw, w = total(write_db, "WRITE_SIZE", sub)
     out = {"kernel": sub, "fetch_dispatches": nf, "write_dispatches": nw,
@@ -29,10 +29,10 @@ def main(fetch_db, write_db, sub):
            "bytes_per_launch_corrected": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
            "bytes_per_launch_uncorrected": (f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
            "correction": "FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KiB units",
-           "command": "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify "
+           "command": command or "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify "
                       "(tools/collect_profiles.sh)"}
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

@@ -4,9 +4,12 @@ events.  Under `rocprofv3 --kernel-trace` + tools/rocpd_gaps.py it shows how muc
 
     python tools/small_forward_probe.py [forwards per batch size, default 40]
 """
+import os
 import sys
 
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from tstar_amd.interface_heuristic import OWLInterface
 

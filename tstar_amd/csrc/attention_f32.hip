@@ -37,7 +37,10 @@
 //    too: a software-pipelined variant (S^T of tile t issued as s, o0, s, o1 with PV of tile t-1 -- three
 //    independent chains, fragments of step r+1 requested before the MFMAs of step r, order pinned with
 //    sched_barrier, LDS-DMA staging; 140 VGPRs = 3 waves / SIMD) measured 113.9 vs 117.9 in a same-session
-//    A/B: dependent-MFMA stalls are not the limiter either, the lost wave of occupancy costs more.
+//    A/B: dependent-MFMA stalls are not the limiter either, the lost wave of occupancy costs more.  Two more same-session
+//    A/Bs against 119.8: the V tile staged TRANSPOSED so that one ds_read_b128 feeds four PV MFMAs (8 b128 instead of 16
+//    ds_read2_b32 per tile, transposing ds_write_b32 staging): 109.3; an XCD-aware block order that keeps the five query
+//    tiles of a head on one L2: 119.8 -- the K/V re-reads already hit.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
