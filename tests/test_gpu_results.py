@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,k,clip", [(3600, 8, None), (3600, 8, (100.7, 460.2)), (14400, 32, None), (40, 8, (3, 11)),
-                                      (10, 10, None)])
+                                      (10, 10, None), (20000, 16, None), (33000, 8, (4000.5, 29000.2))])
 def test_topk_matches_oracle(n, k, clip):
     from oracle import searcher_ref as S
     from tstar_amd.results import topk_seconds

@@ -25,6 +25,23 @@ def _ulp_close(a, b, ulps=4):
 @pytest.mark.parametrize("N,g,seed", [(3600, 4, 0), (3600, 16, 1), (100, 4, 2), (14400, 15, 3), (777, 8, 4), (4097, 7, 5),
                                       (2049, 4, 6), (17, 4, 7), (1009, 10, 8), (19000, 16, 9)])
 def test_l1_injected_confidences(N, g, seed):
+    _run_l1(N, g, seed)
+
+
+def test_l1_randomized_sweep():
+    """The same L1 protocol over 28 seeded random (N, g, K) -- odd lengths, 2x2 to 16x16 grids, K from 1 to 32, videos
+    shorter than one grid (N < g*g: everything is sampled in iteration 0 and the sampler's fallback branch runs)."""
+    rs = np.random.RandomState(20250928)
+    cases = [(10, 4, 3), (16, 4, 16), (40, 6, 5), (33, 6, 1)]
+    while len(cases) < 28:
+        g = int(rs.choice([2, 3, 4, 5, 8, 11, 13, 16]))          # 1x1 has one point per fit: FITPACK needs m > k
+        N = int(rs.randint(max(g * g // 2, 4), 9000))
+        cases.append((N, g, int(rs.randint(1, min(N, 32) + 1))))
+    for i, (N, g, K) in enumerate(cases):
+        _run_l1(N, g, 1000 + i, K=K, max_iters=6)
+
+
+def _run_l1(N, g, seed, K=8, max_iters=12):
     from oracle import searcher_ref as S
     from tstar_amd.interface_searcher import _DeviceState
     n = min(g * g, N)
@@ -36,7 +53,7 @@ def test_l1_injected_confidences(N, g, seed):
     budget = min(1000, N)
     it = 0
     exact_P = 0
-    while budget > 0 and it < 12:
+    while budget > 0 and it < max_iters:
         if it == 0:
             secs = np.arange(0, N, N // n)[:n]
             if len(secs) < n:
@@ -95,18 +112,42 @@ def test_l1_injected_confidences(N, g, seed):
     st.pop_prep()
     p_ref = score / score.sum()
     assert np.array_equal(st.read(3), p_ref)
-    key_ref = rs_ref.choice(N, size=8, replace=False, p=p_ref)
+    key_ref = rs_ref.choice(N, size=K, replace=False, p=p_ref)
     found = []
-    while len(found) < 8:
-        x = rs_dev.random_sample(8 - len(found))
+    while len(found) < K:
+        x = rs_dev.random_sample(K - len(found))
         if found:
             st.exclude(found)
         new = st.draw(x)
         _, first = np.unique(new, return_index=True)
         first.sort()
         found.extend(int(v) for v in new.take(first))
-    assert np.array_equal(np.asarray(found[:8]), key_ref)
-    print(f"N={N} g={g}: {it} iterations, P bit-identical in {exact_P}/{it}")
+    assert np.array_equal(np.asarray(found[:K]), key_ref)
+    print(f"N={N} g={g} K={K}: {it} iterations, P bit-identical in {exact_P}/{it}")
+
+
+@pytest.mark.parametrize("N", [8191, 8192, 8193, 8194, 8200, 9000, 12000, 16384, 16385, 16392, 19000, 33000])
+def test_np_sum_order_beyond_the_ufunc_buffer(N):
+    """np.add.reduce feeds its pairwise inner loop one ufunc buffer (8192 elements) at a time and accumulates the chunk
+    sums left to right, so for N > 8192 `a.sum()` is NOT one pairwise recursion over the whole array.  Dense random
+    values make every summation order visible in the last bits: the normalisations of pop_frames (score / score.sum())
+    and of the sampler (w / w.sum()) must equal numpy's bit for bit."""
+    from oracle import searcher_ref as S
+    from tstar_amd.interface_searcher import _DeviceState
+    for trial in range(3):
+        rs = np.random.RandomState(N * 7 + trial)
+        score = rs.random_sample(N)
+        st = _DeviceState(N, 1e-6, 0.18)
+        st.write(0, score)
+        nnz, total = st.pop_prep()
+        assert nnz == N and total == score.sum()
+        assert np.array_equal(st.read(3), score / score.sum())
+        P, unv = rs.random_sample(N), (rs.random_sample(N) < 0.7).astype(np.float64)
+        st.write(2, P)
+        st.write(1, unv)
+        fb = st.sampler_prep(64, 64 / N)
+        p_ref, fb_ref = S.sampler_weights(P, unv, 64)
+        assert fb == fb_ref and np.array_equal(st.read(3), p_ref)
 
 
 def test_sampler_fallback_branch():

@@ -37,13 +37,23 @@ struct SumProgram {        // numpy pairwise_sum order for length-N arrays
 
 // numpy/_core/src/umath/loops_utils.h.src pairwise sum: n < 8 sequential; n <= 128
 // 8-way unrolled; else split at n/2 rounded down to a multiple of 8.
-static void build_program(int off, int n, std::vector<int>& lo, std::vector<int>& ll, std::vector<signed char>& ops) {
+static void build_pairwise(int off, int n, std::vector<int>& lo, std::vector<int>& ll, std::vector<signed char>& ops) {
     if (n <= 128) { lo.push_back(off); ll.push_back(n); ops.push_back(0); return; }
     int n2 = n / 2;
     n2 -= n2 % 8;
-    build_program(off, n2, lo, ll, ops);
-    build_program(off + n2, n - n2, lo, ll, ops);
+    build_pairwise(off, n2, lo, ll, ops);
+    build_pairwise(off + n2, n - n2, lo, ll, ops);
     ops.push_back(1);
+}
+// np.add.reduce hands the inner loop at most one ufunc buffer (np.getbufsize() = 8192 elements, numpy 1.26 and 2.x) at
+// a time and accumulates the chunks left to right: a.sum() = (pw(a[0:8192]) + pw(a[8192:16384])) + ...  For N <= 8192 that
+// is the plain pairwise sum; beyond it (the 4-hour videos of BASELINE configs[4]) the chunking changes the last bits.
+constexpr int NP_BUFSIZE = 8192;
+static void build_program(int off, int n, std::vector<int>& lo, std::vector<int>& ll, std::vector<signed char>& ops) {
+    for (int c = 0; c < n; c += NP_BUFSIZE) {
+        build_pairwise(off + c, n - c < NP_BUFSIZE ? n - c : NP_BUFSIZE, lo, ll, ops);
+        if (c > 0) ops.push_back(1);
+    }
 }
 
 __device__ double leaf_sum(const double* a, int n) {

@@ -40,6 +40,14 @@ __device__ float np_pairwise_sum_f32(const float* a, int n) {
     return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
 }
 
+// a.sum() as numpy computes it: np.add.reduce feeds the inner loop one ufunc buffer (8192 elements) at a time and
+// accumulates the chunk sums left to right
+__device__ float np_sum_f32(const float* a, int n) {
+    float s = np_pairwise_sum_f32(a, n < 8192 ? n : 8192);
+    for (int c = 8192; c < n; c += 8192) s += np_pairwise_sum_f32(a + c, n - c < 8192 ? n - c : 8192);
+    return s;
+}
+
 __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ P, int N, int start, int end, int k,
                                                     float* __restrict__ full, int* __restrict__ out) {
     __shared__ float s_v[1024];
@@ -55,20 +63,20 @@ __global__ __launch_bounds__(1024) void topk_kernel(const double* __restrict__ P
         full[i] = v;
     }
     __syncthreads();
-    if (t == 0) s_sum = np_pairwise_sum_f32(full, N);
+    if (t == 0) s_sum = np_sum_f32(full, N);
     __syncthreads();
     if (s_sum == 0.f) {                                   // if dist.sum() == 0: dist = ones_like(dist)
         __syncthreads();
         for (int i = t; i < N; i += 1024) full[i] = 1.f;
     }
     __syncthreads();
-    if (t == 0) s_sum = np_pairwise_sum_f32(work, n);
+    if (t == 0) s_sum = np_sum_f32(work, n);
     __syncthreads();
     if (s_sum == 0.f) {                                   // if dist_clip.sum() == 0: ones
         __syncthreads();
         for (int i = t; i < n; i += 1024) work[i] = 1.f;
         __syncthreads();
-        if (t == 0) s_sum = np_pairwise_sum_f32(work, n);
+        if (t == 0) s_sum = np_sum_f32(work, n);
         __syncthreads();
     }
     const float total = s_sum;
