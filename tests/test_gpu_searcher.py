@@ -38,10 +38,12 @@ def test_l1_randomized_sweep():
         N = int(rs.randint(max(g * g // 2, 4), 9000))
         cases.append((N, g, int(rs.randint(1, min(N, 32) + 1))))
     for i, (N, g, K) in enumerate(cases):
-        _run_l1(N, g, 1000 + i, K=K, max_iters=6)
+        _run_l1(N, g, 1000 + i, K=K, max_iters=6, dense=bool(i % 2))
+    for i, (N, g, K) in enumerate([(8193, 16, 8), (9001, 13, 32), (16390, 16, 8), (20011, 8, 5)]):
+        _run_l1(N, g, 2000 + i, K=K, max_iters=5, dense=True)
 
 
-def _run_l1(N, g, seed, K=8, max_iters=12):
+def _run_l1(N, g, seed, K=8, max_iters=12, dense=False):
     from oracle import searcher_ref as S
     from tstar_amd.interface_searcher import _DeviceState
     n = min(g * g, N)
@@ -50,6 +52,9 @@ def _run_l1(N, g, seed, K=8, max_iters=12):
     unv = np.ones(N)
     P = np.ones(N) * 0.6 * 0.3
     rs_dev, rs_ref, gen = np.random.RandomState(seed), np.random.RandomState(seed), np.random.RandomState(seed + 50)
+    if dense:                    # every entry different: any deviation from numpy's operation order shows in the last bits
+        score = gen.random_sample(N) * 0.4 + 1e-3
+        st.write(0, score)
     budget = min(1000, N)
     it = 0
     exact_P = 0
