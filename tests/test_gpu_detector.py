@@ -72,6 +72,24 @@ def test_preprocess_bit_exact(setup, H, W):
     assert np.array_equal(pat.cpu().numpy(), ref_pat)
 
 
+def test_preprocess_random_source_sizes(setup):
+    """Pillow's bicubic resample to 768x768 from 14 seeded random source sizes with dense noise (upscales, 20x decimation,
+    extreme aspect ratios, the 768x768 identity, every grid size 95g x 200g is covered above): resized bytes and patch
+    matrix bit-exact against the oracle (itself bit-equal to the real Pillow / HF image processor)."""
+    from oracle import resize_ref as R
+    rs = np.random.RandomState(123)
+    sizes = [(768, 768), (2, 2), (3, 1500), (1536, 1536), (240, 427), (95, 200)]
+    while len(sizes) < 14:
+        sizes.append((int(rs.randint(4, 1700)), int(rs.randint(4, 3300))))
+    for H, W in sizes:
+        img = rs.randint(0, 256, (1, H, W, 3), dtype=np.uint8)
+        u8, pat = setup["scorer"].debug_preprocess(torch.from_numpy(img).cuda())
+        torch.cuda.synchronize()
+        ref_u8 = R.pil_bicubic_resize(img[0], 768, 768)
+        assert np.array_equal(u8[0].cpu().numpy(), ref_u8), (H, W)
+        assert np.array_equal(pat.cpu().numpy(), R.patchify(R.hf_rescale_normalize(ref_u8))), (H, W)
+
+
 # (380,800,4,4) = the reference's default grid; (285,600,1,1) = a verification frame; (1520,3200,16,16) = BASELINE
 # configs[1] (256 frames per grid image, what bench.py times); (1425,3000,15,15) = configs[4]
 @pytest.mark.parametrize("H,W,rows,cols,B", [(380, 800, 4, 4, 3), (285, 600, 1, 1, 2), (1520, 3200, 16, 16, 2),

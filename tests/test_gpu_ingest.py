@@ -43,6 +43,28 @@ def test_frames_resize_rgb(ow, oh):
         assert np.array_equal(out[k].cpu().numpy(), R.cv_bilinear_resize(fr[k], ow, oh))
 
 
+def test_frames_resize_random_source_sizes():
+    """Random noise frames of 20 seeded random source sizes (upscales, strong decimation, odd sizes, exact 2x / 4x / 1x of
+    the target) to the grid-cell (200x95) and verification (600x285) sizes: bit-exact against the oracle's cv2.resize
+    statement, including its INTER_AREA switch at exactly 2x decimation."""
+    from oracle import resize_ref as R
+    L, lib = _lib()
+    rs = np.random.RandomState(77)
+    sizes = [(190, 400), (380, 800), (95, 200), (570, 1200), (285, 600), (2, 2), (2, 3), (1080, 1920)]
+    while len(sizes) < 20:
+        sizes.append((int(rs.randint(8, 1300)), int(rs.randint(8, 1300))))
+    for H, W in sizes:
+        frames = rs.randint(0, 256, (2, H, W, 3), dtype=np.uint8)
+        d = torch.from_numpy(frames).cuda()
+        idx = torch.tensor([1, 0], dtype=torch.int32, device="cuda")
+        for ow, oh in ((200, 95), (600, 285)):
+            out = torch.empty((2, oh, ow, 3), dtype=torch.uint8, device="cuda")
+            L.check(lib.tstar_frames_resize(d.data_ptr(), 2, H, W, idx.data_ptr(), 2, ow, oh, out.data_ptr(), 0, None))
+            torch.cuda.synchronize()
+            for k, src in enumerate((1, 0)):
+                assert np.array_equal(out[k].cpu().numpy(), R.cv_bilinear_resize(frames[src], ow, oh)), (H, W, ow, oh)
+
+
 def test_nv12_store_matches_rgb_of_converted_frames():
     """NV12 ingest = the RGB ingest applied to the converted frames (conversion fused into the taps)."""
     from oracle import resize_ref as R
