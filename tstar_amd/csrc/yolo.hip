@@ -56,6 +56,17 @@ struct ConvArgs {
     int M;                                                   // B * Ho * Wo
 };
 
+// K is walked in slices of 16 input channels, the ks*ks taps of a slice back to back (the nine shifted reads of one
+// 16-channel activation slice then hit the CU's L1: +2 % over tap-major order).  Every conv kernel uses this order, so
+// their outputs are bit-identical.  Returns the (tap, first input channel) of slice k0 / 16; the weight row of its first
+// k is tap * cin + ci.
+template <int KS>
+__device__ __forceinline__ void slice_pos(const ConvArgs& a, int k0, int& tap, int& ci) {
+    const int sl = k0 / 16;
+    tap = sl % (KS * KS);
+    ci = (sl / (KS * KS)) * 16;
+}
+
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
 // ------------------------------------------------------------------ implicit-GEMM conv on the VALU
@@ -114,8 +125,9 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
     f32x4 ra[2], rw[NWQ];
     auto load_tile = [&](int k0) {
         // k0 is a multiple of 16 and cin % 16 == 0, so the 16-wide slice stays inside one (ky, kx) tap
-        const int tap = k0 / a.cin;
-        const int ci = k0 - tap * a.cin + kq;
+        int tap, ci0;
+        slice_pos<KS>(a, k0, tap, ci0);
+        const int ci = ci0 + kq, krow = tap * a.cin + ci0;
         const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 #pragma unroll
         for (int r = 0; r < NWQ; ++r) {
             f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (wval[r]) w = *reinterpret_cast<const f32x4*>(wrow[r] + k0);
+            if (wval[r]) w = *reinterpret_cast<const f32x4*>(wrow[r] + krow);
             rw[r] = w;
         }
     };
@@ -209,129 +221,18 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 // wave-uniform -- one s_load_dwordx16 from the transposed matrix [K][cout] into SGPRs -- and feeds v_pk_fma_f32 as its
 // scalar operand (channel pairs are the packed halves, the pixel value is broadcast with op_sel).  A lane owns P = 8 (or
 // 4) pixels x 16 channels (128 / 64 accumulators: 2 / 4 waves per SIMD); the four waves of a workgroup share one 64 P-pixel
-// x 16-k activation tile in LDS
-// (pixel-major rows of 16 + 4 floats: the staging ds_write_b128 needs no transposition, the ds_read_b128 of 64 lanes at
-// an 80-byte stride are conflict-free) and take one 16-channel group each.  Per k and wave: 2 ds_read_b128 + 1 s_load
-// for 64 v_pk_fma_f32, a quarter of the LDS traffic per FMA of the tile kernel.  The accumulation order over k is the
-// same sequential (ky, kx, ci) fmaf chain, so both kernels give bit-identical outputs.
-constexpr int SWK = 16, SWLD = SWK + 4, SWN = 64;
+// x 16-k activation tile in LDS and take one 16-channel group each.  Per k and wave: 2 ds_read_b128 + 1 s_load for 64
+// v_pk_fma_f32, a quarter of the LDS traffic per FMA of the tile kernel.  The accumulation order over k is the same
+// sequential fmaf chain (slice_pos), so all conv kernels give bit-identical outputs (tested).
+constexpr int SWK = 16, SWN = 64;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // acc.xy += a.x * w.xy  /  acc.xy += a.y * w.xy   (w in an SGPR pair)
 __device__ __forceinline__ void pkfma_lo(f32x2& acc, f32x2 av, f32x2 w) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(av), "s"(w)); }
 __device__ __forceinline__ void pkfma_hi(f32x2& acc, f32x2 av, f32x2 w) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(av), "s"(w)); }
 
-template <int KS, int P>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 : 4, P == 8 ? 2 : 4))) void conv_sw_kernel(ConvArgs a, int mt, int nt) {
-    constexpr int SWM = 64 * P;                                     // pixels per workgroup: P per lane
-    __shared__ __attribute__((aligned(16))) float As[SWM][SWLD];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // 1-D grid, XCD-aware: each XCD gets a contiguous run of tiles, channel blocks of one pixel tile adjacent, so the nt
-    // workgroups that read the same activation tile (and their 3x3 neighbours) share one L2
-    const int tile = xcd_remap(blockIdx.x, mt * nt);
-    const int m0 = (tile / nt) * SWM;
-    const int cg0 = (tile % nt) * SWN + wave * 16;                   // wave-uniform channel group
-    const bool active = cg0 < a.cout;                                // cout % 16 == 0 (launcher)
-    // staging roles: thread -> pixels (tid / 4) + 64 i, k quad tid % 4.  Per pixel: the element offset of its top-left
-    // tap and one validity bit per tap (padding and the M tail), so a slice costs a bit test, a select and an add per load;
-    // a padded tap reads the zero quad kept behind every activation buffer (zoff) and needs no fix-up afterwards
-    const int kq4 = (tid & 3) * 4, sr0 = tid >> 2;
-    unsigned poff[P], pval[P];
-    {
-        const int hw = a.Ho * a.Wo;
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const int m = m0 + sr0 + 64 * i;
-            const bool ok = m < a.M;
-            const int mm = ok ? m : 0;
-            const int b = mm / hw, rem = mm - b * hw;
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            const int y0 = oy * a.stride - (KS >> 1), x0 = ox * a.stride - (KS >> 1);
-            poff[i] = (unsigned)(((b * a.H + y0) * a.W + x0) * a.src_ld + a.src_off + kq4);   // wraps for y0/x0 = -1; only used with a valid tap
-            unsigned v = 0;
-#pragma unroll
-            for (int t = 0; t < KS * KS; ++t) {
-                const int iy = y0 + t / KS, ix = x0 + t % KS;
-                v |= (unsigned)(ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) << t;
-            }
-            pval[i] = v;
-        }
-    }
-    const int K = KS * KS * a.cin;
-    f32x4 ra[P];
-    auto load_tile = [&](int k0) {
-        // k0 is a multiple of 16 and cin % 16 == 0: a slice stays inside one (ky, kx) tap
-        const int tap = k0 / a.cin, ci = k0 - tap * a.cin;
-        const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
-        const unsigned toff = (unsigned)((ky * a.W + kx) * a.src_ld + ci), tbit = 1u << tap;
-#pragma unroll
-        for (int i = 0; i < P; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.src + ((pval[i] & tbit) ? poff[i] + toff : a.zoff));
-    };
-    f32x2 acc[P][8];
-#pragma unroll
-    for (int j = 0; j < P; ++j)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[j][c] = f32x2{0.f, 0.f};
-    // address space 4 (constant): the weight rows are wave-uniform and never written by this kernel -> s_load_dwordx16
-    typedef __attribute__((address_space(4))) const f32x16 cw16;
-    const float* wcol = a.wt + (active ? cg0 : 0);
-
-    load_tile(0);
-    for (int k0 = 0; k0 < K; k0 += SWK) {
-        // weight rows of the first two k of the slice: in flight across the barriers
-        f32x16 wna = *(const cw16*)(unsigned long long)(wcol + (size_t)k0 * a.cout);
-        f32x16 wnb = *(const cw16*)(unsigned long long)(wcol + (size_t)(k0 + 1) * a.cout);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < P; ++i) *reinterpret_cast<f32x4*>(&As[sr0 + 64 * i][kq4]) = ra[i];
-        __syncthreads();
-        if (k0 + SWK < K) load_tile(k0 + SWK);                     // global loads of the next slice fly during the FMAs
-        if (active) {
-            f32x4 av[P], an[P];
-#pragma unroll
-            for (int j = 0; j < P; ++j) av[j] = *reinterpret_cast<const f32x4*>(&As[lane + 64 * j][0]);
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-#pragma unroll
-                for (int kp = 0; kp < 2; ++kp) {                     // two k per batch of scalar loads
-                    // SMEM returns out of order, so every wait on it is lgkmcnt(0): the wait for this batch is placed HERE,
-                    // before the next batch is issued, and each batch then has two k (128 v_pk_fma_f32) to arrive
-                    asm volatile("" :: "s"(wna[0]), "s"(wnb[0]));
-                    __builtin_amdgcn_sched_barrier(0);
-                    const f32x16 wa = wna, wb = wnb;
-                    const int kn = kq * 4 + kp * 2 + 2;              // compile-time
-                    if (kn < SWK) {
-                        wna = *(const cw16*)(unsigned long long)(wcol + (size_t)(k0 + kn) * a.cout);
-                        wnb = *(const cw16*)(unsigned long long)(wcol + (size_t)(k0 + kn + 1) * a.cout);
-                    }
-                    if (kp == 0 && kq < 3) {
-#pragma unroll
-                        for (int j = 0; j < P; ++j) an[j] = *reinterpret_cast<const f32x4*>(&As[lane + 64 * j][kq * 4 + 4]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const f32x2 w2 = {wa[2 * c], wa[2 * c + 1]};
-#pragma unroll
-                        for (int j = 0; j < P; ++j) pkfma_lo(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const f32x2 w2 = {wb[2 * c], wb[2 * c + 1]};
-#pragma unroll
-                        for (int j = 0; j < P; ++j) pkfma_hi(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (kq < 3) {
-#pragma unroll
-                    for (int j = 0; j < P; ++j) av[j] = an[j];
-                }
-            }
-        }
-    }
-    if (!active) return;
+template <int P>
+__device__ __forceinline__ void conv_sw_epilogue(const ConvArgs& a, f32x2 (&acc)[P][8], int m0, int cg0, int lane) {
     // epilogue: as in the tile kernel; a lane writes 16 consecutive channels of each of its 8 pixels
     const int ch_per_head = a.mode == MODE_ATTN_MUL ? a.cout / a.heads : 1;
     float bias[16];
@@ -362,6 +263,128 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 
             *reinterpret_cast<f32x4*>(a.dst + (size_t)m * a.dst_ld + a.dst_off + nb) = v;
         }
     }
+}
+
+// The activation tile is staged by direct global -> LDS DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write
+// phase) into a double-buffered tile: ONE barrier per slice, and the loads of slice s+1 land in the other
+// buffer while slice s is computed.  A wave instruction fills 1 KB of LDS contiguously (lane L at byte 16 L), so tile rows
+// are un-padded 64-byte pixel rows and the bank-conflict swizzle is applied on the GLOBAL side: slot q of pixel p holds
+// k-quad q ^ ((p >> 2) & 3); the fragment read of k-quad kq then takes slot kq ^ ((lane >> 2) & 3), and the 16 lanes of a
+// ds_read_b128 group (16 consecutive pixels) hit 16 distinct 16-byte slots.
+template <int KS, int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 : 4, P == 8 ? 2 : 4))) void conv_sw_kernel(ConvArgs a, int mt, int nt) {
+    constexpr int SWM = 64 * P;
+    __shared__ __attribute__((aligned(16))) float As[2][SWM][SWK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * SWM;
+    const int cg0 = (tile % nt) * SWN + wave * 16;
+    const bool active = cg0 < a.cout;
+    // staging roles: DMA instruction i of wave w fills pixels (4 i + w) 16 .. +15; lane L -> pixel (L >> 2), slot L & 3
+    unsigned poff[P], pval[P];
+    {
+        const int hw = a.Ho * a.Wo;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int pl = (4 * i + wave) * 16 + (lane >> 2);              // pixel within the tile
+            const int kq = (lane & 3) ^ ((pl >> 2) & 3);                   // the k-quad this slot holds
+            const int m = m0 + pl;
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const int y0 = oy * a.stride - (KS >> 1), x0 = ox * a.stride - (KS >> 1);
+            poff[i] = (unsigned)(((b * a.H + y0) * a.W + x0) * a.src_ld + a.src_off + 4 * kq);
+            unsigned v = 0;
+#pragma unroll
+            for (int t = 0; t < KS * KS; ++t) {
+                const int iy = y0 + t / KS, ix = x0 + t % KS;
+                v |= (unsigned)(ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) << t;
+            }
+            pval[i] = v;
+        }
+    }
+    const int K = KS * KS * a.cin;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto stage = [&](int k0, int buf) {
+        int tap, ci;
+        slice_pos<KS>(a, k0, tap, ci);
+        const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
+        const unsigned toff = (unsigned)((ky * a.W + kx) * a.src_ld + ci), tbit = 1u << tap;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float* g = a.src + ((pval[i] & tbit) ? poff[i] + toff : a.zoff);
+            const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)&As[buf][(4 * i + wave) * 16][0]);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory");
+        }
+    };
+    f32x2 acc[P][8];
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] = f32x2{0.f, 0.f};
+    typedef __attribute__((address_space(4))) const f32x16 cw16;
+    const float* wcol = a.wt + (active ? cg0 : 0);
+    const int xs = ((lane >> 2) & 3) * 4;                                  // read-side swizzle, in floats
+
+    stage(0, 0);
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += SWK) {
+        int wtap, wci;
+        slice_pos<KS>(a, k0, wtap, wci);
+        const float* wrow0 = wcol + (size_t)(wtap * a.cin + wci) * a.cout;   // weight row of the slice's first k
+        f32x16 wna = *(const cw16*)(unsigned long long)(wrow0);
+        f32x16 wnb = *(const cw16*)(unsigned long long)(wrow0 + a.cout);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): this wave's DMA of slice k0 has landed
+        __syncthreads();                                                    // everyone's has, and nobody still reads the other buffer
+        if (k0 + SWK < K) stage(k0 + SWK, cur ^ 1);
+        if (active) {
+            const float* ab = &As[cur][lane][0];
+            f32x4 av[P], an[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) av[j] = *reinterpret_cast<const f32x4*>(ab + j * 64 * SWK + (0 ^ xs));
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {
+                    asm volatile("" :: "s"(wna[0]), "s"(wnb[0]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x16 wa = wna, wb = wnb;
+                    const int kn = kq * 4 + kp * 2 + 2;
+                    if (kn < SWK) {
+                        wna = *(const cw16*)(unsigned long long)(wrow0 + (size_t)kn * a.cout);
+                        wnb = *(const cw16*)(unsigned long long)(wrow0 + (size_t)(kn + 1) * a.cout);
+                    }
+                    if (kp == 0 && kq < 3) {
+#pragma unroll
+                        for (int j = 0; j < P; ++j) an[j] = *reinterpret_cast<const f32x4*>(ab + j * 64 * SWK + ((4 * (kq + 1)) ^ xs));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x2 w2 = {wa[2 * c], wa[2 * c + 1]};
+#pragma unroll
+                        for (int j = 0; j < P; ++j) pkfma_lo(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x2 w2 = {wb[2 * c], wb[2 * c + 1]};
+#pragma unroll
+                        for (int j = 0; j < P; ++j) pkfma_hi(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kq < 3) {
+#pragma unroll
+                    for (int j = 0; j < P; ++j) av[j] = an[j];
+                }
+            }
+        }
+        cur ^= 1;
+    }
+    if (!active) return;
+    conv_sw_epilogue<P>(a, acc, m0, cg0, lane);
 }
 
 // W [cout][K] -> Wt [K][cout], once per model at tstar_yolo_create
