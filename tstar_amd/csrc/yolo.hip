@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 
             const int b = mm / hw, rem = mm - b * hw;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
             const int y0 = oy * a.stride - (KS >> 1), x0 = ox * a.stride - (KS >> 1);
-            poff[i] = (unsigned)(((b * a.H + y0) * a.W + x0) * a.src_ld + a.src_off + 4 * kq);
+            poff[i] = 4u * (unsigned)(((b * a.H + y0) * a.W + x0) * a.src_ld + a.src_off + 4 * kq);   // BYTE offset from a.src; wraps for y0 / x0 = -1, only used with a valid tap
             unsigned v = 0;
 #pragma unroll
             for (int t = 0; t < KS * KS; ++t) {
@@ -311,12 +311,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 
         int tap, ci;
         slice_pos<KS>(a, k0, tap, ci);
         const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
-        const unsigned toff = (unsigned)((ky * a.W + kx) * a.src_ld + ci), tbit = 1u << tap;
+        const unsigned toff = 4u * (unsigned)((ky * a.W + kx) * a.src_ld + ci), tbit = 1u << tap, zoffb = 4u * a.zoff;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const float* g = a.src + ((pval[i] & tbit) ? poff[i] + toff : a.zoff);
+            // scalar base + 32-bit byte offset (zoff < 2^30 elements, launcher): bit test, add, select per load
+            const unsigned off = (pval[i] & tbit) ? poff[i] + toff : zoffb;
             const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)&As[buf][(4 * i + wave) * 16][0]);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(la) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(a.src), "s"(la) : "memory");
         }
     };
     f32x2 acc[P][8];
