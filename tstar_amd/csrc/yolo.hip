@@ -967,7 +967,8 @@ struct YoloLevel { int e_buf, r_buf, size, stride, param_off; float logit_scale,
 
 struct tstar_yolo {
     float* d_blob = nullptr; size_t n_blob = 0;
-    float* d_blob_t = nullptr;                                // conv matrices transposed to [K][cout], at the same offsets
+    float* d_blob_t = nullptr;                                // conv matrices transposed to [K][cout], each at a 64-byte aligned offset
+    std::vector<size_t> wt_off;                               // ... wt_off[op] (floats), one entry per op
     std::vector<float> h_small;                               // host copy of the per-level scalars
     std::vector<YoloOp> ops;
     std::vector<int> buf_h, buf_w, buf_c;
@@ -1056,13 +1057,19 @@ int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, cons
     }
     hipError_t e = hipMalloc(&h->d_blob, n_blob * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->d_blob, h_blob, n_blob * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&h->d_blob_t, n_blob * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(h->d_blob_t, 0, n_blob * sizeof(float));
+    // transposed copies for the scalar-weight kernel: a weight row of 16 channels is one 64-byte scalar-cache line
+    size_t n_t = 0;
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        const int* w = h->ops[i].w;
+        h->wt_off.push_back(n_t);
+        if (w[0] == OP_CONV) n_t += ((size_t)w[6] * w[7] * w[7] * w[3] + 15) / 16 * 16;
+    }
+    if (e == hipSuccess) e = hipMalloc(&h->d_blob_t, (n_t + 16) * sizeof(float));
     for (size_t i = 0; i < h->ops.size() && e == hipSuccess; ++i) {
         const int* w = h->ops[i].w;
         if (w[0] != OP_CONV) continue;
         const int cout = w[6], K = w[7] * w[7] * w[3];
-        hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(cout * K, 256)), dim3(256), 0, 0, h->d_blob + w[10], h->d_blob_t + w[10], cout, K);
+        hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(cout * K, 256)), dim3(256), 0, 0, h->d_blob + w[10], h->d_blob_t + h->wt_off[i], cout, K);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1147,13 +1154,13 @@ int tstar_yolo_set_class_weights(tstar_yolo* h, int query_set, const double* h_c
 }
 
 static int run_program(tstar_yolo* h, int B, const int* d_image_set, hipStream_t s) {
-    for (const YoloOp& op : h->ops) {
-        const int* w = op.w;
+    for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+        const int* w = h->ops[oi].w;
         if (w[0] == OP_CONV) {
             ConvArgs a{};
             a.src = h->bufs[w[1]]; a.src_ld = h->buf_c[w[1]]; a.src_off = w[2]; a.cin = w[3]; a.H = h->buf_h[w[1]]; a.W = h->buf_w[w[1]];
             a.dst = h->bufs[w[4]]; a.dst_ld = h->buf_c[w[4]]; a.dst_off = w[5]; a.cout = w[6]; a.Ho = h->buf_h[w[4]]; a.Wo = h->buf_w[w[4]];
-            a.ks = w[7]; a.stride = w[8]; a.act = w[9]; a.w = h->d_blob + w[10]; a.wt = h->d_blob_t + w[10]; a.bias = w[11] >= 0 ? h->d_blob + w[11] : nullptr;
+            a.ks = w[7]; a.stride = w[8]; a.act = w[9]; a.w = h->d_blob + w[10]; a.wt = h->d_blob_t + h->wt_off[oi]; a.bias = w[11] >= 0 ? h->d_blob + w[11] : nullptr;
             a.mode = w[12];
             if (a.mode != MODE_PLAIN) { a.aux = h->bufs[w[13]]; a.aux_ld = h->buf_c[w[13]]; a.aux_off = w[14]; a.heads = h->buf_c[w[13]]; }
             a.M = B * a.Ho * a.Wo;
