@@ -366,6 +366,47 @@ def test_l2_teacher_forced_reference_default_grid():
     print(f"reference-default grid teacher-forced: keyframes {ts_ref}, {n_ver} verification calls over 63 iterations")
 
 
+def test_l2_teacher_forced_randomized():
+    """Ten seeded random searches -- video length, grid, K, threshold (from 'everything verifies' to 'nothing does'),
+    budget (fraction or absolute), one to three targets, zero to two cues -- closed-loop on the HIP pipeline, then the
+    recorded confidences replayed through the oracle searcher: same sampled seconds every iteration, same histories,
+    same keyframes, and no detector batch the reference loop would not have asked for."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_video
+    rs = np.random.RandomState(4242)
+    objs = ["couch", "tv", "chair", "dog", "ball", "lamp", "cup"]
+    h = OWLInterface(synthetic_seed=0, max_batch=16)
+    for case in range(10):
+        g = int(rs.choice([2, 3, 4, 5, 8]))
+        N = int(rs.randint(max(2 * g * g, 40), 2600))
+        K = int(rs.randint(1, 13))
+        thr = float(rs.choice([0.004, 0.02, 0.3, 0.6, 0.95]))
+        budget = float(rs.choice([0.1, 0.35, 0.9])) if rs.rand() < 0.6 else int(rs.randint(g * g, 6 * g * g))
+        pick = list(rs.permutation(objs))
+        targets, cues = pick[:int(rs.randint(1, 4))], pick[3:3 + int(rs.randint(0, 3))]
+        seed = int(rs.randint(0, 10000))
+        rec = _Recorder(h)
+        s = TStarSearcher(synthetic_video(N, seed=100 + case), h, targets, cues, search_nframes=K, image_grid_shape=(g, g),
+                          search_budget=budget, confidence_threshold=thr, rng=np.random.RandomState(seed), keep_visual_history=False)
+        log = []
+        orig = s.sample_frames
+        s.sample_frames = lambda num, orig=orig, log=log: (lambda r: (log.append(list(r[0])), r)[1])(orig(num))
+        frames, ts = s.search()
+        h.score_batch = rec._orig
+        ref, ts_ref = _replay_through_oracle(rec, h, targets, cues, N, g, K, budget, thr, seed)
+        assert [it["secs"] for it in ref.trace] == log, case
+        assert ts_ref == [float(t) for t in ts], case
+        assert len(ref.Score_history) == s.iterations
+        for i in range(s.iterations):
+            assert np.array_equal(np.asarray(s.Score_history[i]), ref.Score_history[i]), (case, i)
+            assert np.array_equal(np.asarray(s.non_visiting_history[i]), ref.unvisited_history[i]), (case, i)
+            assert np.array_equal(np.asarray(s.P_history[i]), ref.P_history[i]), (case, i)
+        assert np.array_equal(s.score_distribution, ref.score)
+        print(f"case {case}: N={N} g={g} K={K} thr={thr} budget={budget} targets={targets} cues={cues}: {s.iterations} iterations, "
+              f"{sum(len(it['verify']) for it in ref.trace)} verifications, keyframes {ts_ref}")
+
+
 def test_generic_heuristic_path_matches_fast_path():
     """A foreign duck-typed heuristic (only the reference surface) must give the same search."""
     from tstar_amd.interface_searcher import TStarSearcher
