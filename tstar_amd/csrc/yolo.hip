@@ -223,7 +223,10 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 // 4) pixels x 16 channels (128 / 64 accumulators: 2 / 4 waves per SIMD); the four waves of a workgroup share one 64 P-pixel
 // x 16-k activation tile in LDS and take one 16-channel group each.  Per k and wave: 2 ds_read_b128 + 1 s_load for 64
 // v_pk_fma_f32, a quarter of the LDS traffic per FMA of the tile kernel.  The accumulation order over k is the same
-// sequential fmaf chain (slice_pos), so all conv kernels give bit-identical outputs (tested).
+// sequential fmaf chain (slice_pos), so all conv kernels give bit-identical outputs (tested).  Measured on the way (L model,
+// B = 32 forward, ms): tile kernel only 80.5; + this kernel 73.3 (8 pixels per lane) / 70.0 (per-layer 4 or 8); DMA staging
+// + slice-major K 68.3; 32-bit saddr addressing 67.0.  No gain: a second register stage of global prefetch, touching the
+// next batch's weight rows to pre-load the scalar cache, 64-byte aligned rows alone.
 constexpr int SWK = 16, SWN = 64;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
