@@ -122,45 +122,48 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
 
-    f32x4 ra[2], rw[NWQ];
-    auto load_tile = [&](int k0) {
+    // global -> register staging, three slices deep: a small layer runs one workgroup (or none) per CU, so nothing else hides
+    // the L2 latency of a slice's loads; issued three slices ahead they have ~1.5 us to land.  Loads are unconditional
+    // (a padded tap / out-of-range row reads a valid dummy address and is zeroed when the slice is stored; past the last
+    // slice, slice 0 is re-read and dropped), which keeps them back to back and lets the in-order vmcnt wait be exact.
+    struct Stage { f32x4 ra[2], rw[NWQ]; unsigned ok; };
+    auto load_tile = [&](Stage& st, int k0) {
         // k0 is a multiple of 16 and cin % 16 == 0, so the 16-wide slice stays inside one (ky, kx) tap
+        if (k0 >= K) k0 = 0;
         int tap, ci0;
         slice_pos<KS>(a, k0, tap, ci0);
         const int ci = ci0 + kq, krow = tap * a.cin + ci0;
         const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
+        st.ok = 0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int iy = ay[r] + ky, ix = ax[r] + kx;
             const bool ok = aval[r] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(a.src + ((size_t)(ab[r] * a.H + iy) * a.W + ix) * a.src_ld + a.src_off + ci);
-            ra[r] = v;
+            const size_t off = ok ? ((size_t)(ab[r] * a.H + iy) * a.W + ix) * a.src_ld + a.src_off + ci : (size_t)0;
+            st.ra[r] = *reinterpret_cast<const f32x4*>(a.src + off);
+            st.ok |= ok ? 1u << r : 0u;
         }
 #pragma unroll
-        for (int r = 0; r < NWQ; ++r) {
-            f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (wval[r]) w = *reinterpret_cast<const f32x4*>(wrow[r] + krow);
-            rw[r] = w;
-        }
+        for (int r = 0; r < NWQ; ++r) st.rw[r] = *reinterpret_cast<const f32x4*>(wrow[r] + krow);   // rows >= cout read row 0: their outputs are never stored
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const Stage& st) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r) {
+            const f32x4 v = ((st.ok >> r) & 1) ? st.ra[r] : z;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[kq + e][(ar0 + r * 64 + rot) & (CBM - 1)] = ra[r][e];
+            for (int e = 0; e < 4; ++e) As[kq + e][(ar0 + r * 64 + rot) & (CBM - 1)] = v[e];
+        }
 #pragma unroll
         for (int r = 0; r < NWQ; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Ws[kq + e][(ar0 + r * 64 + rot) & (BN - 1)] = rw[r][e];
+            for (int e = 0; e < 4; ++e) Ws[kq + e][(ar0 + r * 64 + rot) & (BN - 1)] = st.rw[r][e];
     };
-
-    load_tile(0);
-    for (int k0 = 0; k0 < K; k0 += CBK) {
+    auto step = [&](Stage& st, int k0) {
         __syncthreads();
-        store_tile();
+        store_tile(st);
         __syncthreads();
-        if (k0 + CBK < K) load_tile(k0 + CBK);               // global loads of the next slice fly during the FMAs
+        load_tile(st, k0 + 3 * CBK);
 #pragma unroll
         for (int k = 0; k < CBK; ++k) {
             const int rk = (k >> 3) * 8;                             // compile-time after unrolling
@@ -180,6 +183,15 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
                     }
                 }
         }
+    };
+    Stage s0, s1, s2;
+    load_tile(s0, 0);
+    load_tile(s1, CBK);
+    load_tile(s2, 2 * CBK);
+    for (int k0 = 0;;) {                                             // the back edge always follows step(s2, ..)
+        step(s0, k0); k0 += CBK; if (k0 >= K) break;
+        step(s1, k0); k0 += CBK; if (k0 >= K) break;
+        step(s2, k0); k0 += CBK; if (k0 >= K) break;
     }
     // epilogue: bias, activation, residual (after the activation: DarknetBottleneck adds the identity last) or the
     // max-sigmoid attention gate (after project_conv's BatchNorm, no activation)
