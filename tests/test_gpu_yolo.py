@@ -103,18 +103,19 @@ def test_other_model_scales(scale):
 
 
 def test_conv_kernels_bit_identical():
-    """The three VALU convolution kernels (LDS-tiled, scalar-weight with 8 / 4 pixels per lane) accumulate every output
-    in the same (ky, kx, ci) fmaf order: a whole forward is BIT-identical whichever kernel the per-layer policy picks.
+    """The VALU convolution kernels (LDS-tiled with 128- / 64-pixel tiles, scalar-weight with 8 / 4 pixels per lane) accumulate
+    every output in the same fmaf order: a whole forward is BIT-identical whichever kernel the per-layer policy picks.
     The policy is read from the environment once per process, so each variant runs in its own interpreter."""
     import os
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "yolo_conv_variant_probe.py")
     out = {}
-    for name, env in [("tile", {"TSTAR_YOLO_SW": "0"}), ("sw8", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "8"}),
+    for name, env in [("tile128", {"TSTAR_YOLO_SW": "0", "TSTAR_YOLO_TM": "8"}), ("tile64", {"TSTAR_YOLO_SW": "0", "TSTAR_YOLO_TM": "4"}),
+                      ("sw8", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "8"}),
                       ("sw4", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "4"}), ("policy", {})]:
         e = dict(os.environ, **env)
-        for k in ("TSTAR_YOLO_SW", "TSTAR_YOLO_SW_P", "TSTAR_YOLO_SW_MIN"):
+        for k in ("TSTAR_YOLO_SW", "TSTAR_YOLO_SW_P", "TSTAR_YOLO_SW_MIN", "TSTAR_YOLO_TM", "TSTAR_YOLO_TM_MIN", "TSTAR_YOLO_TN"):
             if k not in env:
                 e.pop(k, None)
         p = subprocess.run([sys.executable, probe, "s", "3"], env=e, capture_output=True, text=True, timeout=600)

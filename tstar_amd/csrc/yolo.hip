@@ -70,16 +70,19 @@ __device__ __forceinline__ void slice_pos(const ConvArgs& a, int k0, int& tap, i
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
 // ------------------------------------------------------------------ implicit-GEMM conv on the VALU
-// Workgroup tile 128 pixels x BN channels (BN = 64 or 128), K slices of 16; a lane owns 8 pixels x TN channels (TN = 4
-// or 8).  Per k the lane reads 2 + TN/4 LDS quads for 8 TN FMAs: with TN = 8 the LDS pipe (shared by the CU's four
+// Workgroup tile 16 TM pixels x BN channels (TM = 8 or 4: 128 or 64 pixels; BN = 64 or 128), K slices of 16; a lane owns
+// TM pixels x TN channels (TN = 4 or 8).  The 64-pixel tile serves layers with fewer than 512 128-pixel tiles (small maps,
+// small batches): twice the workgroups, so CUs hold two that overlap each other's barriers and load latency (L model
+// forward: B = 1 15.7 -> 10.1 ms, B = 4 19.3 -> 16.2 ms).  Per k the lane reads 2 + TN/4 LDS quads for 8 TN FMAs: with TN = 8 the LDS pipe (shared by the CU's four
 // SIMDs) carries 4 reads per 64 FMAs instead of 3 per 32, which is what keeps the VALU fed on the >= 128-channel layers.
 // LDS rows k >= 8 are rotated by 8 floats: the transposing ds_write_b32 of lanes with k-quad 0 / 2 (and 1 / 3) would
 // otherwise land on the same banks (row stride = 16 mod 32 banks); the b128 fragment reads stay 16-byte aligned.
-constexpr int CBM = 128, CBK = 16, CLD_A = CBM + 4;
+constexpr int CBK = 16;
 
-template <int KS, int TN>
+template <int KS, int TN, int TM>
 __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int nt) {
     constexpr int BN = 16 * TN, CLD_W = BN + 4, NWQ = BN / 64;       // NWQ weight float4 per thread per slice
+    constexpr int CBM = 16 * TM, CLD_A = CBM + 4, NAQ = CBM / 64;    // TM = 8 (4): 128 (64) pixels per workgroup, NAQ activation float4 per thread
     __shared__ __attribute__((aligned(16))) float As[CBK][CLD_A];
     __shared__ __attribute__((aligned(16))) float Ws[CBK][CLD_W];
     const int tid = threadIdx.x;
@@ -91,10 +94,10 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
     const int kq = (tid & 3) * 4;
     const int rot = (kq >> 3) * 8;                                   // column rotation of LDS rows k >= 8
     const int ar0 = tid >> 2;
-    int ab[2], ay[2], ax[2];
-    bool aval[2];
+    int ab[NAQ], ay[NAQ], ax[NAQ];
+    bool aval[NAQ];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NAQ; ++r) {
         const int m = m0 + ar0 + r * 64;
         aval[r] = m < a.M;
         const int mm = aval[r] ? m : 0;
@@ -116,9 +119,9 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 
     // compute roles: 8 rows x TN cols per lane
     const int tx = tid & 15, ty = tid >> 4;                          // cols tx*4 (+64).., rows ty*8..
-    float acc[8][TN];
+    float acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
 
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
     // the L2 latency of a slice's loads; issued three slices ahead they have ~1.5 us to land.  Loads are unconditional
     // (a padded tap / out-of-range row reads a valid dummy address and is zeroed when the slice is stored; past the last
     // slice, slice 0 is re-read and dropped), which keeps them back to back and lets the in-order vmcnt wait be exact.
-    struct Stage { f32x4 ra[2], rw[NWQ]; unsigned ok; };
+    struct Stage { f32x4 ra[NAQ], rw[NWQ]; unsigned ok; };
     auto load_tile = [&](Stage& st, int k0) {
         // k0 is a multiple of 16 and cin % 16 == 0, so the 16-wide slice stays inside one (ky, kx) tap
         if (k0 >= K) k0 = 0;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
         const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
         st.ok = 0;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NAQ; ++r) {
             const int iy = ay[r] + ky, ix = ax[r] + kx;
             const bool ok = aval[r] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             const size_t off = ok ? ((size_t)(ab[r] * a.H + iy) * a.W + ix) * a.src_ld + a.src_off + ci : (size_t)0;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
     auto store_tile = [&](const Stage& st) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NAQ; ++r) {
             const f32x4 v = ((st.ok >> r) & 1) ? st.ra[r] : z;
 #pragma unroll
             for (int e = 0; e < 4; ++e) As[kq + e][(ar0 + r * 64 + rot) & (CBM - 1)] = v[e];
@@ -167,8 +170,9 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 #pragma unroll
         for (int k = 0; k < CBK; ++k) {
             const int rk = (k >> 3) * 8;                             // compile-time after unrolling
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[k][(ty * 8 + rk) & (CBM - 1)]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[k][(ty * 8 + 4 + rk) & (CBM - 1)]);
+            f32x4 av[TM / 4];
+#pragma unroll
+            for (int h2 = 0; h2 < TM / 4; ++h2) av[h2] = *reinterpret_cast<const f32x4*>(&As[k][(ty * TM + 4 * h2 + rk) & (CBM - 1)]);
             f32x4 w4[TN / 4];
 #pragma unroll
             for (int q = 0; q < TN / 4; ++q) w4[q] = *reinterpret_cast<const f32x4*>(&Ws[k][(tx * 4 + q * 64 + rk) & (BN - 1)]);
@@ -178,8 +182,8 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        acc[i][q * 4 + j] = fmaf(a0[i], w4[q][j], acc[i][q * 4 + j]);
-                        acc[4 + i][q * 4 + j] = fmaf(a1[i], w4[q][j], acc[4 + i][q * 4 + j]);
+#pragma unroll
+                        for (int h2 = 0; h2 < TM / 4; ++h2) acc[4 * h2 + i][q * 4 + j] = fmaf(av[h2][i], w4[q][j], acc[4 * h2 + i][q * 4 + j]);
                     }
                 }
         }
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
         if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + nb);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + ty * 8 + i;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + ty * TM + i;
             if (m >= a.M) continue;
             f32x4 v;
 #pragma unroll
@@ -507,15 +511,26 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         }
         if (prof) prof_stop(PROF_CONV, s);
     } else if (tiled) {
-        // 128-channel tiles (8 x 8 outputs per lane) when the layer has the channels and enough pixels to fill the chip
+        // 128-channel tiles (8 x 8 outputs per lane) when the layer has the channels and enough pixels to fill the chip;
+        // 64-pixel tiles (4 x 4 per lane) when 128-pixel tiles would leave CUs without a workgroup to overlap with
         static const int tn_env = [] { const char* e = getenv("TSTAR_YOLO_TN"); return e ? atoi(e) : 0; }();
-        const bool wide = tn_env ? tn_env == 8 : (a.cout % 128 == 0 && (long long)cdiv(a.M, CBM) * (a.cout / 128) >= 512);
-        const int mt = cdiv(a.M, CBM), nt = cdiv(a.cout, wide ? 128 : 64);
+        static const int tm_env = [] { const char* e = getenv("TSTAR_YOLO_TM"); return e ? atoi(e) : 0; }();
+        static const int tm_min = [] { const char* e = getenv("TSTAR_YOLO_TM_MIN"); return e ? atoi(e) : 512; }();
+        const bool wide = tn_env ? tn_env == 8 : (a.cout % 128 == 0 && (long long)cdiv(a.M, 128) * (a.cout / 128) >= 512);
+        const bool small = !wide && (tm_env ? tm_env == 4 : (long long)cdiv(a.M, 128) * cdiv(a.cout, 64) < tm_min);
+        const int mt = cdiv(a.M, small ? 64 : 128), nt = cdiv(a.cout, wide ? 128 : 64);
         const dim3 grid(mt * nt);
         const bool prof = prof_enabled();
         if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
-        if (a.ks == 1) { if (wide) hipLaunchKernelGGL((conv_valu_kernel<1, 8>), grid, dim3(256), 0, s, a, mt, nt); else hipLaunchKernelGGL((conv_valu_kernel<1, 4>), grid, dim3(256), 0, s, a, mt, nt); }
-        else { if (wide) hipLaunchKernelGGL((conv_valu_kernel<3, 8>), grid, dim3(256), 0, s, a, mt, nt); else hipLaunchKernelGGL((conv_valu_kernel<3, 4>), grid, dim3(256), 0, s, a, mt, nt); }
+        if (a.ks == 1) {
+            if (wide) hipLaunchKernelGGL((conv_valu_kernel<1, 8, 8>), grid, dim3(256), 0, s, a, mt, nt);
+            else if (small) hipLaunchKernelGGL((conv_valu_kernel<1, 4, 4>), grid, dim3(256), 0, s, a, mt, nt);
+            else hipLaunchKernelGGL((conv_valu_kernel<1, 4, 8>), grid, dim3(256), 0, s, a, mt, nt);
+        } else {
+            if (wide) hipLaunchKernelGGL((conv_valu_kernel<3, 8, 8>), grid, dim3(256), 0, s, a, mt, nt);
+            else if (small) hipLaunchKernelGGL((conv_valu_kernel<3, 4, 4>), grid, dim3(256), 0, s, a, mt, nt);
+            else hipLaunchKernelGGL((conv_valu_kernel<3, 4, 8>), grid, dim3(256), 0, s, a, mt, nt);
+        }
         if (prof) prof_stop(PROF_CONV, s);
     } else {
         TSTAR_REQUIRE(a.mode == MODE_PLAIN, "yolo conv: the direct form has no fused residual / gate");
