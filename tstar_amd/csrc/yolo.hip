@@ -83,6 +83,7 @@ template <int KS, int TN, int TM>
 __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int nt) {
     constexpr int BN = 16 * TN, CLD_W = BN + 4, NWQ = BN / 64;       // NWQ weight float4 per thread per slice
     constexpr int CBM = 16 * TM, CLD_A = CBM + 4, NAQ = CBM / 64;    // TM = 8 (4): 128 (64) pixels per workgroup, NAQ activation float4 per thread
+    constexpr int DEPTH = TN == 8 ? 1 : 3;                           // register prefetch depth in slices (the 8 x 8 tile has no registers to spare)
     __shared__ __attribute__((aligned(16))) float As[CBK][CLD_A];
     __shared__ __attribute__((aligned(16))) float Ws[CBK][CLD_W];
     const int tid = threadIdx.x;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
 
-    // global -> register staging, three slices deep: a small layer runs one workgroup (or none) per CU, so nothing else hides
+    // global -> register staging, DEPTH = three slices deep (one for the 8 x 8 tile): a small layer runs one workgroup (or none) per CU, so nothing else hides
     // the L2 latency of a slice's loads; issued three slices ahead they have ~1.5 us to land.  Loads are unconditional
     // (a padded tap / out-of-range row reads a valid dummy address and is zeroed when the slice is stored; past the last
     // slice, slice 0 is re-read and dropped), which keeps them back to back and lets the in-order vmcnt wait be exact.
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
         __syncthreads();
         store_tile(st);
         __syncthreads();
-        load_tile(st, k0 + 3 * CBK);
+        load_tile(st, k0 + DEPTH * CBK);
 #pragma unroll
         for (int k = 0; k < CBK; ++k) {
             const int rk = (k >> 3) * 8;                             // compile-time after unrolling
@@ -188,14 +189,20 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
                 }
         }
     };
-    Stage s0, s1, s2;
-    load_tile(s0, 0);
-    load_tile(s1, CBK);
-    load_tile(s2, 2 * CBK);
-    for (int k0 = 0;;) {                                             // the back edge always follows step(s2, ..)
-        step(s0, k0); k0 += CBK; if (k0 >= K) break;
-        step(s1, k0); k0 += CBK; if (k0 >= K) break;
-        step(s2, k0); k0 += CBK; if (k0 >= K) break;
+    if constexpr (DEPTH == 3) {
+        Stage s0, s1, s2;
+        load_tile(s0, 0);
+        load_tile(s1, CBK);
+        load_tile(s2, 2 * CBK);
+        for (int k0 = 0;;) {                                         // the back edge always follows step(s2, ..)
+            step(s0, k0); k0 += CBK; if (k0 >= K) break;
+            step(s1, k0); k0 += CBK; if (k0 >= K) break;
+            step(s2, k0); k0 += CBK; if (k0 >= K) break;
+        }
+    } else {
+        Stage s0;
+        load_tile(s0, 0);
+        for (int k0 = 0; k0 < K; k0 += CBK) step(s0, k0);
     }
     // epilogue: bias, activation, residual (after the activation: DarknetBottleneck adds the identity last) or the
     // max-sigmoid attention gate (after project_conv's BatchNorm, no activation)
