@@ -61,7 +61,7 @@ struct ConvArgs {
 // their outputs are bit-identical.  Returns the (tap, first input channel) of slice k0 / 16; the weight row of its first
 // k is tap * cin + ci.
 template <int KS>
-__device__ __forceinline__ void slice_pos(const ConvArgs& a, int k0, int& tap, int& ci) {
+__device__ __forceinline__ void slice_pos(int k0, int& tap, int& ci) {
     const int sl = k0 / 16;
     tap = sl % (KS * KS);
     ci = (sl / (KS * KS)) * 16;
@@ -110,12 +110,10 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
     }
     const int K = KS * KS * a.cin;
     const float* wrow[NWQ];
-    bool wval[NWQ];
 #pragma unroll
     for (int r = 0; r < NWQ; ++r) {
         const int wn = n0 + ar0 + r * 64;
-        wval[r] = wn < a.cout;
-        wrow[r] = a.w + (size_t)(wval[r] ? wn : 0) * K + kq;
+        wrow[r] = a.w + (size_t)(wn < a.cout ? wn : 0) * K + kq;   // rows >= cout read row 0: their outputs are never stored
     }
 
     // compute roles: 8 rows x TN cols per lane
@@ -135,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
         // k0 is a multiple of 16 and cin % 16 == 0, so the 16-wide slice stays inside one (ky, kx) tap
         if (k0 >= K) k0 = 0;
         int tap, ci0;
-        slice_pos<KS>(a, k0, tap, ci0);
+        slice_pos<KS>(k0, tap, ci0);
         const int ci = ci0 + kq, krow = tap * a.cin + ci0;
         const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
         st.ok = 0;
@@ -244,8 +242,10 @@ __global__ __launch_bounds__(256) void conv_valu_kernel(ConvArgs a, int mt, int 
 // wave-uniform -- one s_load_dwordx16 from the transposed matrix [K][cout] into SGPRs -- and feeds v_pk_fma_f32 as its
 // scalar operand (channel pairs are the packed halves, the pixel value is broadcast with op_sel).  A lane owns P = 8 (or
 // 4) pixels x 16 channels (128 / 64 accumulators: 2 / 4 waves per SIMD); the four waves of a workgroup share one 64 P-pixel
-// x 16-k activation tile in LDS and take one 16-channel group each.  Per k and wave: 2 ds_read_b128 + 1 s_load for 64
-// v_pk_fma_f32, a quarter of the LDS traffic per FMA of the tile kernel.  The accumulation order over k is the same
+// x 16-k activation tile in LDS and take one 16-channel group each.  Per k and wave (P = 8): 2 ds_read_b128 + 1 s_load for 64
+// v_pk_fma_f32, a quarter of the LDS traffic per FMA of the tile kernel.  Scalar loads are issued in batches of two k with the
+// (out-of-order, hence lgkmcnt(0)) wait placed before the next batch; padded taps read a zero quad kept behind every
+// activation buffer instead of branching.  The accumulation order over k is the same
 // sequential fmaf chain (slice_pos), so all conv kernels give bit-identical outputs (tested).  Measured on the way (L model,
 // B = 32 forward, ms): tile kernel only 80.5; + this kernel 73.3 (8 pixels per lane) / 70.0 (per-layer 4 or 8); DMA staging
 // + slice-major K 68.3; 32-bit saddr addressing 67.0.  No gain: a second register stage of global prefetch, touching the
@@ -259,7 +259,7 @@ __device__ __forceinline__ void pkfma_hi(f32x2& acc, f32x2 av, f32x2 w) { asm("v
 
 template <int P>
 __device__ __forceinline__ void conv_sw_epilogue(const ConvArgs& a, f32x2 (&acc)[P][8], int m0, int cg0, int lane) {
-    // epilogue: as in the tile kernel; a lane writes 16 consecutive channels of each of its 8 pixels
+    // as in the tile kernel; a lane writes 16 consecutive channels of each of its P pixels
     const int ch_per_head = a.mode == MODE_ATTN_MUL ? a.cout / a.heads : 1;
     float bias[16];
 #pragma unroll
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto stage = [&](int k0, int buf) {
         int tap, ci;
-        slice_pos<KS>(a, k0, tap, ci);
+        slice_pos<KS>(k0, tap, ci);
         const int ky = KS == 1 ? 0 : tap / KS, kx = KS == 1 ? 0 : tap - ky * KS;
         const unsigned toff = 4u * (unsigned)((ky * a.W + kx) * a.src_ld + ci), tbit = 1u << tap, zoffb = 4u * a.zoff;
 #pragma unroll
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 
     int cur = 0;
     for (int k0 = 0; k0 < K; k0 += SWK) {
         int wtap, wci;
-        slice_pos<KS>(a, k0, wtap, wci);
+        slice_pos<KS>(k0, wtap, wci);
         const float* wrow0 = wcol + (size_t)(wtap * a.cin + wci) * a.cout;   // weight row of the slice's first k
         f32x16 wna = *(const cw16*)(unsigned long long)(wrow0);
         f32x16 wnb = *(const cw16*)(unsigned long long)(wrow0 + a.cout);
