@@ -103,7 +103,8 @@ def test_other_model_scales(scale):
 
 
 def test_conv_kernels_bit_identical():
-    """The VALU convolution kernels (LDS-tiled with 128- / 64-pixel tiles, scalar-weight with 8 / 4 pixels per lane) accumulate
+    """The VALU convolution kernels (LDS-tiled with 128- / 64-pixel tiles, scalar-weight with 8 / 4 pixels per lane, and its
+    halo-tile form for 3x3 layers) accumulate
     every output in the same fmaf order: a whole forward is BIT-identical whichever kernel the per-layer policy picks.
     The policy is read from the environment once per process, so each variant runs in its own interpreter."""
     import os
@@ -111,11 +112,12 @@ def test_conv_kernels_bit_identical():
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "yolo_conv_variant_probe.py")
     out = {}
-    for name, env in [("tile128", {"TSTAR_YOLO_SW": "0", "TSTAR_YOLO_TM": "8"}), ("tile64", {"TSTAR_YOLO_SW": "0", "TSTAR_YOLO_TM": "4"}),
-                      ("sw8", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "8"}),
-                      ("sw4", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "4"}), ("policy", {})]:
+    for name, env in [("tile128", {"TSTAR_YOLO_SW": "0", "TSTAR_YOLO_TM": "8", "TSTAR_YOLO_HALO": "0"}), ("tile64", {"TSTAR_YOLO_SW": "0", "TSTAR_YOLO_TM": "4", "TSTAR_YOLO_HALO": "0"}),
+                      ("sw8", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "8", "TSTAR_YOLO_HALO": "0"}),
+                      ("sw4", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "4", "TSTAR_YOLO_HALO": "0"}),
+                      ("halo", {"TSTAR_YOLO_HALO": "2"}), ("policy", {})]:
         e = dict(os.environ, **env)
-        for k in ("TSTAR_YOLO_SW", "TSTAR_YOLO_SW_P", "TSTAR_YOLO_SW_MIN", "TSTAR_YOLO_TM", "TSTAR_YOLO_TM_MIN", "TSTAR_YOLO_TN"):
+        for k in ("TSTAR_YOLO_SW", "TSTAR_YOLO_SW_P", "TSTAR_YOLO_SW_MIN", "TSTAR_YOLO_TM", "TSTAR_YOLO_TM_MIN", "TSTAR_YOLO_TN", "TSTAR_YOLO_HALO"):
             if k not in env:
                 e.pop(k, None)
         p = subprocess.run([sys.executable, probe, "s", "3"], env=e, capture_output=True, text=True, timeout=600)

@@ -19,6 +19,8 @@
 //   conv_sw_kernel       the same convolution with the weights as SCALAR operands (s_load_dwordx16 rows of the transposed
 //                        matrix feeding v_pk_fma_f32 from SGPRs): a quarter of the LDS traffic per FMA; used for the
 //                        layers with >= 400 workgroups of 512 pixels x 64 channels (see the kernel's comment).
+//   conv_halo_kernel     its form for 3x3 / stride-1 layers: an 8 x 40 output patch per workgroup, the 10 x 42 halo patch of a
+//                        16-channel slice staged once and read by all nine taps.
 //   pool5 / upcopy / attn / letterbox / head_decode  HBM-bound elementwise & small reductions (wave shuffles).
 //   sort_nms_kernel      per image: bitonic sort of the (score, anchor, class) candidates, class-aware greedy NMS run by
 //                        ONE wavefront (kept boxes in LDS, lanes test them in parallel, __ballot decides), top-k.
@@ -414,6 +416,152 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 
     conv_sw_epilogue<P>(a, acc, m0, cg0, lane);
 }
 
+// ------------------------------------------------------------------ scalar-weight 3x3 conv with a halo tile
+// For 3x3 / stride-1 layers whose map is a multiple of 8 x 40 pixels (the 160-, 80- and 40-wide maps of a 640 x 640 input):
+// a workgroup owns an 8 x 40 patch of ONE image and stages its 10 x 42 halo patch of a 16-channel slice ONCE (9 DMA
+// instructions per wave, out-of-image pixels from the zero quad); the nine taps then read shifted windows of it -- every
+// shift is an immediate ds_read offset -- instead of re-loading a shifted tile per tap as conv_sw_kernel does: 6.5x fewer
+// DMA loads and two barriers per 144 k instead of one per 16.  Halo pixels are 80-byte rows (16 floats + one pad quad,
+// filled by a fifth dummy lane so that a DMA instruction still writes 1 KB contiguously): consecutive pixels at an
+// 80-byte stride make the ds_read_b128 of a 16-lane group conflict-free.  A lane owns 5 pixels x 16 channels (3 waves per
+// SIMD).  Same (ci slice, tap, k) fmaf order as every other conv kernel: bit-identical outputs.
+constexpr int HTH = 8, HTW = 40, HHW = HTW + 2, HNP = (HTH + 2) * HHW, HP = HTH * HTW / 64, HLD = SWK + 4;
+constexpr int HDMA = (HNP * 5 + 63) / 64;                           // DMA instructions per slice (33), 9 rounds of 4 waves
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_halo_kernel(ConvArgs a, int mt, int nt) {
+    __shared__ __attribute__((aligned(16))) float Hs[HDMA * 64 / 5 + 1][HLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int cg0 = (tile % nt) * SWN + wave * 16;
+    const bool active = cg0 < a.cout;
+    const int tpr = a.W / HTW, tpi = (a.H / HTH) * tpr;              // tiles per row / per image
+    const int pt = tile / nt, b = pt / tpi, y0 = ((pt % tpi) / tpr) * HTH, x0 = (pt % tpr) * HTW;
+    // staging roles: DMA instruction i = wave + 4 it fills halo slots 64 i .. 64 i + 63; slot s = halo pixel s / 5, quad s % 5
+    constexpr int NIT = (HDMA + 3) / 4;
+    unsigned hoff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int sidx = (wave + 4 * it) * 64 + lane;
+        const int hp = sidx / 5, q = sidx - hp * 5;
+        const int hy = hp / HHW, hx = hp - hy * HHW;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool ok = hp < HNP && q < 4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        hoff[it] = ok ? 4u * (unsigned)(((b * a.H + iy) * a.W + ix) * a.src_ld + a.src_off + 4 * q) : 0xffffffffu;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned zoffb = 4u * a.zoff;
+    auto stage = [&](int ci0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (wave + 4 * it < HDMA) {                                    // wave-uniform
+                const unsigned off = hoff[it] == 0xffffffffu ? zoffb : hoff[it] + 4u * (unsigned)ci0;
+                const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)&Hs[0][0]) + (unsigned)(wave + 4 * it) * 1024u;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(a.src), "s"(la) : "memory");
+            }
+        }
+    };
+    // compute roles: lane -> pixels p = lane + 64 j of the 8 x 40 patch; hb[j] = its top-left tap in the halo patch (floats)
+    int hb[HP];
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        const int p = lane + 64 * j, r = p / HTW, c = p - r * HTW;
+        hb[j] = (r * HHW + c) * HLD;
+    }
+    f32x2 acc[HP][8];
+#pragma unroll
+    for (int j = 0; j < HP; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] = f32x2{0.f, 0.f};
+    typedef __attribute__((address_space(4))) const f32x16 cw16;
+    const float* wcol = a.wt + (active ? cg0 : 0);
+    const float* hs = &Hs[0][0];
+
+    for (int ci0 = 0; ci0 < a.cin; ci0 += SWK) {
+        __syncthreads();                                                    // everybody is done with the previous slice's patch
+        stage(ci0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
+        __syncthreads();
+        if (!active) continue;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int toff = (ky * HHW + kx) * HLD;                         // floats
+            const float* wrow0 = wcol + (size_t)(tap * a.cin + ci0) * a.cout;
+            f32x16 wna = *(const cw16*)(unsigned long long)(wrow0);
+            f32x16 wnb = *(const cw16*)(unsigned long long)(wrow0 + a.cout);
+            f32x4 av[HP], an[HP];
+#pragma unroll
+            for (int j = 0; j < HP; ++j) av[j] = *reinterpret_cast<const f32x4*>(hs + hb[j] + toff);
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {
+                    asm volatile("" :: "s"(wna[0]), "s"(wnb[0]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x16 wa = wna, wb = wnb;
+                    const int kn = kq * 4 + kp * 2 + 2;
+                    if (kn < SWK) {
+                        wna = *(const cw16*)(unsigned long long)(wrow0 + (size_t)kn * a.cout);
+                        wnb = *(const cw16*)(unsigned long long)(wrow0 + (size_t)(kn + 1) * a.cout);
+                    }
+                    if (kp == 0 && kq < 3) {
+#pragma unroll
+                        for (int j = 0; j < HP; ++j) an[j] = *reinterpret_cast<const f32x4*>(hs + hb[j] + toff + 4 * (kq + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x2 w2 = {wa[2 * c], wa[2 * c + 1]};
+#pragma unroll
+                        for (int j = 0; j < HP; ++j) pkfma_lo(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x2 w2 = {wb[2 * c], wb[2 * c + 1]};
+#pragma unroll
+                        for (int j = 0; j < HP; ++j) pkfma_hi(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kq < 3) {
+#pragma unroll
+                    for (int j = 0; j < HP; ++j) av[j] = an[j];
+                }
+            }
+        }
+    }
+    if (!active) return;
+    // epilogue (as conv_sw_epilogue, with the patch's pixel mapping)
+    const int ch_per_head = a.mode == MODE_ATTN_MUL ? a.cout / a.heads : 1;
+    float bias[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) bias[c] = a.bias ? a.bias[cg0 + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        const int p = lane + 64 * j, r = p / HTW, c0 = p - r * HTW;
+        const size_t m = ((size_t)b * a.H + y0 + r) * a.W + x0 + c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[j][2 * q + (e >> 1)][e & 1] + bias[4 * q + e];
+                if (a.act == YACT_SILU) t = silu(t);
+                v[e] = t;
+            }
+            const int nb = cg0 + 4 * q;
+            if (a.mode == MODE_RESIDUAL) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(a.aux + m * a.aux_ld + a.aux_off + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            } else if (a.mode == MODE_ATTN_MUL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= a.aux[m * a.aux_ld + a.aux_off + (nb + e) / ch_per_head];
+            }
+            *reinterpret_cast<f32x4*>(a.dst + m * a.dst_ld + a.dst_off + nb) = v;
+        }
+    }
+}
+
 // W [cout][K] -> Wt [K][cout], once per model at tstar_yolo_create
 __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int K) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -503,7 +651,20 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const bool sw_ok = tiled && a.wt && a.cout % 16 == 0 && a.zoff != 0 && a.zoff < (1u << 30);   // byte offsets fit 32 bits
     static const int sw_min = [] { const char* e = getenv("TSTAR_YOLO_SW_MIN"); return e ? atoi(e) : 400; }();
     static const int sw_p_env = [] { const char* e = getenv("TSTAR_YOLO_SW_P"); return e ? atoi(e) : 0; }();
-    if (sw_ok && (sw_env < 0 ? sw_blocks >= sw_min : sw_env > 0)) {
+    // halo form of the scalar-weight kernel for 3x3 / stride-1 layers on 8 x 40-divisible maps: from 320 workgroups up it beats
+    // both other kernels on every such layer (B = 32: 10-15 % per layer; B = 8: 221 vs 266 us at 320 workgroups, 445 vs 272
+    // at 160 -- profiles/r02_yolo_conv_halo_by_layer_b*.md)
+    static const int halo_env = [] { const char* e = getenv("TSTAR_YOLO_HALO"); return e ? atoi(e) : -1; }();
+    const bool halo_ok = sw_ok && a.ks == 3 && a.stride == 1 && a.H % HTH == 0 && a.W % HTW == 0 && a.Ho == a.H && a.Wo == a.W;
+    const long long halo_wgs = halo_ok ? (long long)(a.M / (HTH * HTW)) * cdiv(a.cout, SWN) : 0;
+    if (halo_ok && (halo_env < 0 ? halo_wgs >= 320 : halo_env > 1)) {
+        const int B = a.M / (a.H * a.W);
+        const int mt = B * (a.H / HTH) * (a.W / HTW), nt = cdiv(a.cout, SWN);
+        const bool prof = prof_enabled();
+        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
+        hipLaunchKernelGGL(conv_halo_kernel, dim3(mt * nt), dim3(256), 0, s, a, mt, nt);
+        if (prof) prof_stop(PROF_CONV, s);
+    } else if (sw_ok && (sw_env < 0 ? sw_blocks >= sw_min : sw_env > 0)) {
         const int sw_p = sw_p_env ? sw_p_env : (sw_blocks >= 800 ? 4 : 8);
         const int mt = cdiv(a.M, 64 * sw_p), nt = cdiv(a.cout, SWN);
         const dim3 grid(mt * nt);
