@@ -16,12 +16,14 @@ python $ROOT/tools/rocpd_stats.py "$DBY" --window-ms "$WINY" > "$OUT/${TAG}_yolo
 rm -rf /tmp/prof_yolo2
 rocprofv3 --kernel-trace -d /tmp/prof_yolo2 -o kt -- python $ROOT/tools/yolo_forward_probe.py 32 > "$OUT/${TAG}_yolo_forward_probe.log" 2>&1
 python $ROOT/tools/rocpd_shapes.py "$(find /tmp/prof_yolo2 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_kernel_shapes_b32.md"
-for V in "tile 0 8" "sw8 1 8" "sw4 1 4"; do
+# per-layer comparison of the conv kernels, each forced on every layer it can run (the launcher's policy thresholds come from
+# this table); halo = the halo form wherever eligible, the default policy elsewhere
+for V in "tile 0 8 0" "sw8 1 8 0" "sw4 1 4 0" "halo -1 8 2"; do
     set -- $V
     rm -rf /tmp/prof_yc_$1
-    TSTAR_YOLO_SW=$2 TSTAR_YOLO_SW_P=$3 rocprofv3 --kernel-trace -d /tmp/prof_yc_$1 -o kt -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2>&1
+    TSTAR_YOLO_SW=$2 TSTAR_YOLO_SW_P=$3 TSTAR_YOLO_HALO=$4 rocprofv3 --kernel-trace -d /tmp/prof_yc_$1 -o kt -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2>&1
 done
-python $ROOT/tools/rocpd_conv_align.py 7 tile=$(find /tmp/prof_yc_tile -name '*.db' | head -1) sw8=$(find /tmp/prof_yc_sw8 -name '*.db' | head -1) sw4=$(find /tmp/prof_yc_sw4 -name '*.db' | head -1) > "$OUT/${TAG}_yolo_conv_kernels_by_layer.md"
+python $ROOT/tools/rocpd_conv_align.py 7 tile=$(find /tmp/prof_yc_tile -name '*.db' | head -1) sw8=$(find /tmp/prof_yc_sw8 -name '*.db' | head -1) sw4=$(find /tmp/prof_yc_sw4 -name '*.db' | head -1) halo=$(find /tmp/prof_yc_halo -name '*.db' | head -1) > "$OUT/${TAG}_yolo_conv_kernels_by_layer.md"
 rm -rf /tmp/prof_yolo3
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d /tmp/prof_yolo3 -o pmc -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2> "$OUT/rocprof_yolo_pmc.err"
 python $ROOT/tools/rocpd_pmc.py "$(find /tmp/prof_yolo3 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_pmc_valu_by_kernel.md"
