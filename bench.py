@@ -63,9 +63,10 @@ def parse():
                     help="independent searches in flight per GPU (host threads, one HIP stream + one scorer "
                          "workspace each); 2 fills kernel tails and gives ~+5 %% throughput, but overlapping "
                          "launches inflate per-launch durations, so the roofline leg is reported at 1")
-    ap.add_argument("--lockstep", type=int, default=4,
+    ap.add_argument("--lockstep", type=int, default=0,
                     help="independent (video, question) items advanced in lock-step per detector batch "
-                         "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time")
+                         "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time; default 4 "
+                         "with the OWL-ViT backend, 8 with YOLO-World (its small grid forwards gain from B = 8: +8 %%)")
     ap.add_argument("--heuristic", choices=["owl", "yolo"], default="owl",
                     help="detector backend: owl = OWL-ViT-B/32 (configs[1], the headline); yolo = YOLO-World-v2-L on the f32 VALU, no "
                          "MFMA (BASELINE configs[3]; parity of that model is unpinned: its source is not in the reference tree)")
@@ -86,7 +87,10 @@ def parse():
                          "the reference sees: one solo search and 16 videos in lock-step, untimed by the driver)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.lockstep <= 0:
+        args.lockstep = 8 if args.heuristic == "yolo" else 4
+    return args
 
 
 def make_searcher(heuristic, item, g, k=8):

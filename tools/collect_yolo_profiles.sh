@@ -28,13 +28,13 @@ rm -rf /tmp/prof_yolo3
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d /tmp/prof_yolo3 -o pmc -- python $ROOT/tools/yolo_forward_probe.py 32 > /dev/null 2> "$OUT/rocprof_yolo_pmc.err"
 python $ROOT/tools/rocpd_pmc.py "$(find /tmp/prof_yolo3 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_pmc_valu_by_kernel.md"
 # fabric-side traffic of the convolutions, on the bench command itself (same launch population as its roofline.achieved)
-YB="$PY --heuristic yolo --steps 4 --warmup 0 --no-cpu-baseline --no-verify"
+YB="$PY --heuristic yolo --steps 8 --warmup 0 --no-cpu-baseline --no-verify"
 rm -rf /tmp/prof_yolo4
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_yolo4 -o pmc -- $YB > /dev/null 2>> "$OUT/rocprof_yolo_pmc.err"
 rm -rf /tmp/prof_yolo5
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_yolo5 -o pmc -- $YB > /dev/null 2>> "$OUT/rocprof_yolo_pmc.err"
-python $ROOT/tools/rocpd_traffic.py "$(find /tmp/prof_yolo4 -name '*.db' | head -1)" "$(find /tmp/prof_yolo5 -name '*.db' | head -1)" "conv_valu|conv_sw" \
-    "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --heuristic yolo --steps 4 --warmup 0 --no-cpu-baseline --no-verify (tools/collect_yolo_profiles.sh)" > "$OUT/${TAG}_yolo_pmc_conv_traffic.json"
+python $ROOT/tools/rocpd_traffic.py "$(find /tmp/prof_yolo4 -name '*.db' | head -1)" "$(find /tmp/prof_yolo5 -name '*.db' | head -1)" "conv_valu|conv_sw|conv_halo" \
+    "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --heuristic yolo --steps 8 --warmup 0 --no-cpu-baseline --no-verify (tools/collect_yolo_profiles.sh)" > "$OUT/${TAG}_yolo_pmc_conv_traffic.json"
 cp "$OUT/${TAG}_yolo_pmc_conv_traffic.json" "$ROOT/profiles/${TAG}_yolo_pmc_conv_traffic.json"
 $PY --heuristic yolo --steps 8 --warmup 1 > "$OUT/${TAG}_bench_yolo.json" 2>> "$OUT/bench_yolo.err"
 ls -la "$OUT" | grep yolo
