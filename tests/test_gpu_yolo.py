@@ -102,11 +102,13 @@ def test_other_model_scales(scale):
     det.close()
 
 
-def test_conv_kernels_bit_identical():
+@pytest.mark.parametrize("scale,batch", [("s", 3), ("m", 2)])
+def test_conv_kernels_bit_identical(scale, batch):
     """The VALU convolution kernels (LDS-tiled with 128- / 64-pixel tiles, scalar-weight with 8 / 4 pixels per lane, and its
     halo-tile form for 3x3 layers) accumulate
     every output in the same fmaf order: a whole forward is BIT-identical whichever kernel the per-layer policy picks.
-    The policy is read from the environment once per process, so each variant runs in its own interpreter."""
+    The policy is read from the environment once per process, so each variant runs in its own interpreter.  Scale M has
+    channel counts that are not multiples of 64 (48, 96, 192 ...): partially filled channel blocks."""
     import os
     import subprocess
     import sys
@@ -120,7 +122,7 @@ def test_conv_kernels_bit_identical():
         for k in ("TSTAR_YOLO_SW", "TSTAR_YOLO_SW_P", "TSTAR_YOLO_SW_MIN", "TSTAR_YOLO_TM", "TSTAR_YOLO_TM_MIN", "TSTAR_YOLO_TN", "TSTAR_YOLO_HALO"):
             if k not in env:
                 e.pop(k, None)
-        p = subprocess.run([sys.executable, probe, "s", "3"], env=e, capture_output=True, text=True, timeout=600)
+        p = subprocess.run([sys.executable, probe, scale, str(batch)], env=e, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         out[name] = [ln for ln in p.stdout.splitlines() if ln.startswith("SHA")][0]
     assert len(set(out.values())) == 1, out
