@@ -252,3 +252,42 @@ def test_interface_surface_and_search_replay():
     _, tb = b.search()
     assert [float(t) for t in tb] == [float(t) for t in ts] and np.array_equal(b.score_distribution, s.score_distribution)
     print(f"yolo search: keyframes {ts_ref}, {s.detector_calls} detector calls, {s.frames_scored} frames scored")
+
+
+def test_search_replay_randomized():
+    """Six seeded random searches on the YOLO-World backend (scale S) -- video length, grid, K, threshold, budget, targets
+    and cues -- closed-loop on the HIP pipeline, the recorded confidences replayed through the oracle searcher: the same
+    sampled seconds every iteration, the same histories and keyframes, no detector batch the reference loop would not ask
+    for."""
+    from oracle import replay
+    from tstar_amd.interface_heuristic import initialize_heuristic
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_video
+    rs = np.random.RandomState(777)
+    objs = ["couch", "tv", "chair", "dog", "ball", "lamp", "cup"]
+    h = initialize_heuristic("yolo-World", synthetic_seed=1, scale="s", max_batch=16)
+    for case in range(6):
+        g = int(rs.choice([2, 3, 4, 5]))
+        N = int(rs.randint(max(2 * g * g, 40), 1500))
+        K = int(rs.randint(1, 10))
+        thr = float(rs.choice([0.05, 0.3, 0.6, 0.95]))
+        budget = float(rs.choice([0.1, 0.3])) if rs.rand() < 0.6 else int(rs.randint(g * g, 5 * g * g))
+        pick = list(rs.permutation(objs))
+        targets, cues = [str(x) for x in pick[:int(rs.randint(1, 3))]], [str(x) for x in pick[3:3 + int(rs.randint(0, 3))]]
+        seed = int(rs.randint(0, 10000))
+        rec = replay.Recorder(h, keep_images=False)
+        s = TStarSearcher(video_path=synthetic_video(N, seed=300 + case), heuristic=h, target_objects=targets, cue_objects=cues,
+                          search_nframes=K, image_grid_shape=(g, g), search_budget=budget, confidence_threshold=thr,
+                          rng=np.random.RandomState(seed), keep_visual_history=False)
+        log = []
+        orig = s.sample_frames
+        s.sample_frames = lambda num, orig=orig, log=log: (lambda r: (log.append(list(r[0])), r)[1])(orig(num))
+        _, ts = s.search()
+        rec.restore()
+        ref, ts_ref = replay.replay_through_oracle(rec.calls, h.texts, targets, cues, N, g, K, budget, thr, seed)
+        assert [it["secs"] for it in ref.trace] == log, case
+        assert ts_ref == [float(t) for t in ts], case
+        assert np.array_equal(s.score_distribution, ref.score), case
+        for i in range(s.iterations):
+            assert np.array_equal(np.asarray(s.P_history[i]), ref.P_history[i]), (case, i)
+        print(f"case {case}: N={N} g={g} K={K} thr={thr} budget={budget} {targets} {cues}: {s.iterations} iterations, keyframes {ts_ref}")
