@@ -614,6 +614,50 @@ def test_lockstep_group_equals_sequential_searches():
         search_lockstep([TStarSearcher(stores[0], h, ["a"], [], image_grid_shape=(4, 4))])
 
 
+def test_lockstep_randomized_groups():
+    """Three seeded random lock-step groups of 5-7 heterogeneous items (video length and storage format, K, threshold,
+    budget, one to three targets, cues; the grid is common to a group) against the same items searched one by one: the
+    same keyframes, frames, score distributions, call counts and final P, bit for bit -- items leave the group at
+    different iterations (early stops, budgets), and every image of a batch is scored against its own query set."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.lockstep import search_lockstep
+    from tstar_amd.video import synthetic_video, synthetic_video_nv12
+    rs = np.random.RandomState(99)
+    objs = ["couch", "tv", "chair", "dog", "ball", "lamp", "cup", "a red car"]
+    h = OWLInterface(synthetic_seed=0, max_batch=16)
+    for grp in range(3):
+        g = int(rs.choice([2, 3, 4]))
+        n_items = int(rs.randint(5, 8))
+        specs = []
+        for i in range(n_items):
+            N = int(rs.randint(max(2 * g * g, 30), 700))
+            pick = [str(x) for x in rs.permutation(objs)]
+            specs.append(dict(store=(synthetic_video_nv12 if rs.rand() < 0.3 else synthetic_video)(N, seed=500 + 10 * grp + i),
+                              t=pick[:int(rs.randint(1, 4))], c=pick[4:4 + int(rs.randint(0, 3))], K=int(rs.randint(1, 9)),
+                              thr=float(rs.choice([0.004, 0.3, 0.6, 0.95], p=[0.15, 0.25, 0.4, 0.2])), b=float(rs.choice([0.1, 0.3, 0.6])),
+                              seed=int(rs.randint(0, 10000))))
+
+        def make(sp):
+            return TStarSearcher(sp["store"], h, list(sp["t"]), list(sp["c"]), search_nframes=sp["K"], image_grid_shape=(g, g),
+                                 search_budget=sp["b"], confidence_threshold=sp["thr"], rng=np.random.RandomState(sp["seed"]),
+                                 keep_visual_history=False)
+
+        seq = []
+        for sp in specs:
+            s = make(sp)
+            fr, ts = s.search()
+            seq.append((fr, ts, s.score_distribution, s.frames_scored, s.detector_calls, s.iterations, s.P_history[-1]))
+        group = [make(sp) for sp in specs]
+        res = search_lockstep(group)
+        for i in range(n_items):
+            assert res[i][1] == seq[i][1] and np.array_equal(res[i][0], seq[i][0]), (grp, i)
+            assert np.array_equal(group[i].score_distribution, seq[i][2]), (grp, i)
+            assert (group[i].frames_scored, group[i].detector_calls, group[i].iterations) == seq[i][3:6], (grp, i)
+            assert group[i].P_history[-1] == seq[i][6], (grp, i)
+        print(f"group {grp}: grid {g}x{g}, {n_items} items, iterations {[x[5] for x in seq]}")
+
+
 def test_query_sets_are_independent():
     """Per-image query sets: a batch scored against slots 1 and 2 equals two single-slot calls."""
     from tstar_amd.interface_heuristic import OWLInterface
