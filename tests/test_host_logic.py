@@ -349,3 +349,49 @@ def test_history_helpers_match_the_reference_calls(tmp_path):
     paths = H.save_frames(imgs, [3.0, 10.5, 7], str(tmp_path))
     assert [os.path.basename(p) for p in paths] == ["frame_0_at_3.00s.jpg", "frame_1_at_10.50s.jpg", "frame_2_at_7.00s.jpg"]
     assert Image.open(paths[1]).size == (40, 24)
+
+
+def test_shard_interleave_property():
+    """For every (n_items, world) the rank-major all-gather order maps back to item order, including worlds larger than the
+    item count (empty shards) and ragged last rounds."""
+    from hypothesis import given, settings, strategies as st
+    from tstar_amd import sharding as Sh
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 70), st.integers(1, 16))
+    def prop(n_items, world):
+        rows = [[i, 3 * i + 1] for i in range(n_items)]
+        shards = [Sh.shard_items(n_items, world, r) for r in range(world)]
+        assert sorted(sum(shards, [])) == list(range(n_items))                   # a partition
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1    # balanced
+        gathered = [rows[i] for s in shards for i in s]                          # what gather_keyframes returns (padding dropped)
+        assert Sh.interleave_by_item(gathered, n_items, world) == rows
+    prop()
+
+
+def test_y4m_header_round_trip_and_rejection(tmp_path):
+    """parse_y4m_header on streams written by write_y4m (random even sizes, frame rates, frame counts) and on malformed
+    ones: wrong magic, odd dimensions, non-4:2:0 chroma, missing FRAME marker -- each a ValueError naming the file, the
+    way the reference's reader reports a file it cannot open."""
+    from hypothesis import given, settings, strategies as st
+    from tstar_amd.video import parse_y4m_header, write_y4m
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.integers(1, 12), st.integers(1, 10), st.integers(0, 4), st.sampled_from([(1, 1), (25, 1), (30000, 1001), (2, 3)]))
+    def prop(hw, hh, n, fps):
+        w, h = 2 * hw, 2 * hh
+        rs = np.random.RandomState(w * 100 + h)
+        p = str(tmp_path / f"v_{w}_{h}_{n}_{fps[0]}.y4m")
+        write_y4m(p, rs.randint(0, 256, (max(n, 1), h * 3 // 2, w), dtype=np.uint8)[:max(n, 1)], fps=fps)
+        hd = parse_y4m_header(p)
+        assert (hd["w"], hd["h"], hd["n_frames"], hd["fps_frac"]) == (w, h, max(n, 1), fps)
+        assert hd["frame_bytes"] == w * h * 3 // 2 and abs(hd["fps"] - fps[0] / fps[1]) < 1e-12
+    prop()
+    bad = {"magic": b"YUV4MPEG W4 H4 F1:1\nFRAME\n" + bytes(24), "odd": b"YUV4MPEG2 W5 H4 F1:1\nFRAME\n" + bytes(30),
+           "chroma": b"YUV4MPEG2 W4 H4 F1:1 C444\nFRAME\n" + bytes(48), "noframe": b"YUV4MPEG2 W4 H4 F1:1\nXRAME\n" + bytes(24),
+           "rate": b"YUV4MPEG2 W4 H4 F0:1\nFRAME\n" + bytes(24), "nosize": b"YUV4MPEG2 F1:1\nFRAME\n" + bytes(24)}
+    for name, blob in bad.items():
+        p = tmp_path / f"bad_{name}.y4m"
+        p.write_bytes(blob)
+        with pytest.raises(ValueError, match="Cannot open video file"):
+            parse_y4m_header(str(p))
