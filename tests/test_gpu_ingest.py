@@ -46,7 +46,7 @@ def test_frames_resize_rgb(ow, oh):
 def test_frames_resize_random_source_sizes():
     """Random noise frames of 20 seeded random source sizes (upscales, strong decimation, odd sizes, exact 2x / 4x / 1x of
     the target) to the grid-cell (200x95) and verification (600x285) sizes: bit-exact against the oracle's cv2.resize
-    statement, including its INTER_AREA switch at exactly 2x decimation."""
+    statement (at exactly 2x decimation, where cv2 switches to INTER_AREA, the two formulas coincide)."""
     from oracle import resize_ref as R
     L, lib = _lib()
     rs = np.random.RandomState(77)
