@@ -40,7 +40,9 @@
 //    A/B: dependent-MFMA stalls are not the limiter either, the lost wave of occupancy costs more.  Two more same-session
 //    A/Bs against 119.8: the V tile staged TRANSPOSED so that one ds_read_b128 feeds four PV MFMAs (8 b128 instead of 16
 //    ds_read2_b32 per tile, transposing ds_write_b32 staging): 109.3; an XCD-aware block order that keeps the five query
-//    tiles of a head on one L2: 119.8 -- the K/V re-reads already hit.
+//    tiles of a head on one L2: 119.8 -- the K/V re-reads already hit; 2-wave workgroups with 64 queries per wave (two Q
+//    fragments share every K / V fragment read: half the LDS fragment traffic per MFMA, 2 + 4 independent MFMA chains, 235
+//    VGPRs = 2 waves / SIMD): 114.7 vs 119.2 -- the LDS fragment reads are not the limiter either.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
