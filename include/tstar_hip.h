@@ -237,6 +237,10 @@ int tstar_searcher_read(tstar_searcher* s, int which, double* h_out, void* strea
  * such as PyTorch-ROCm already carries is reused); TSTAR_RCCL_LIB overrides the library name. */
 #define TSTAR_COMM_ID_BYTES 128
 typedef struct tstar_comm tstar_comm;
+/* binds RCCL in THIS process without touching any other rank (0 = usable).  tstar_comm_create is collective, so hosts
+ * call this on every rank and agree on the outcome first: a rank that cannot load RCCL must not leave the others
+ * blocked inside ncclCommInitRank. */
+int tstar_comm_available(void);
 int tstar_comm_unique_id(void* h_id /* TSTAR_COMM_ID_BYTES bytes */);
 int tstar_comm_create(tstar_comm** out, const void* h_id, int world, int rank);
 int tstar_comm_destroy(tstar_comm* c);

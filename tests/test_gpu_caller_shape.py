@@ -50,18 +50,6 @@ def test_dataset_loop_call_shapes(heuristic, tmp_path):
         assert searcher.image_grid_iters[0][0].shape == (380, 800, 3)
         assert len(searcher.detect_bbox_iters) == len(searcher.image_grid_iters)
         assert heuristic.texts[-1] == [" "] and [t[0] for t in heuristic.texts[:-1]] == it["targets"] + it["cues"]
-        # the framework's visual-history files (tstar_amd/history.py) from this search's attributes
-        from PIL import Image
-        from tstar_amd import history as H
-        hist = tmp_path / f"hist{len(results)}"
-        hist.mkdir()
-        paths = H.save_frames(frames, result["keyframe_timestamps"], str(hist))
-        assert [os.path.basename(p) for p in paths] == [n for n, _ in fw.saved["frames"]]
-        assert np.abs(np.asarray(Image.open(paths[0]).convert("RGB"), np.int32) - frames[0].astype(np.int32)).mean() < 3.0   # JPEG q95
-        gif = Image.open(H.save_searching_iterations(searcher, str(hist)))
-        # Pillow merges consecutive identical frames into one longer frame, so the GIF can hold fewer than were passed
-        assert 1 <= gif.n_frames <= len(searcher.detect_annotot_iters) and gif.size == (800, 380) and gif.info["duration"] >= 1000
-        assert os.path.getsize(H.plot_and_save_scores(searcher, str(hist))) > 10000
     out = tmp_path / "results.json"
     CS.dump_results(results, str(out))
     back = json.load(open(out))

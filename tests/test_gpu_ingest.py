@@ -200,3 +200,18 @@ def test_y4m_decode_front_end(tmp_path):
             V.open_video(str(pb))
     with pytest.raises(ValueError, match="Cannot open video file"):
         V.open_video(str(tmp_path / "missing.y4m"))
+    # sizes the device repack cannot take are refused before anything is allocated; a stream whose frame headers vary in
+    # length is refused at the first frame that does not start with its marker
+    odd = str(tmp_path / "odd.y4m")
+    V.write_y4m(odd, np.zeros((2, 30 * 3 // 2, 42), np.uint8))
+    with pytest.raises(ValueError, match="multiple of 64"):
+        V.load_y4m(odd)
+    blob = bytearray(open(path2, "rb").read())
+    hd2 = V.parse_y4m_header(path2)
+    at = hd2["data_offset"] + 3 * (hd2["frame_header_bytes"] + hd2["frame_bytes"])
+    blob[at:at + 6] = b"FRAME "                                           # frame 3 now carries a (longer) parameterised header
+    blob[at + 6:at + 6] = b"Ip\n"
+    shifted = str(tmp_path / "shifted.y4m")
+    open(shifted, "wb").write(bytes(blob) + bytes(hd2["frame_bytes"]))
+    with pytest.raises(ValueError, match="no FRAME marker where frame 4"):
+        V.load_y4m(shifted, chunk=16)

@@ -70,7 +70,7 @@ def test_detector_vs_oracle(yolo, H, W, rows, cols, B):
             assert mask[cell] == want
 
 
-@pytest.mark.parametrize("scale", ["s", "m", "x"])
+@pytest.mark.parametrize("scale", ["s", "m", "x", "xl"])
 def test_other_model_scales(scale):
     """The layer program is data: YOLO-World-v2-S / M / X (other widths, depths, head counts -- X is what the reference's
     hard-coded config names) run through the same kernels; dense scores vs the CPU statement, selection teacher-forced."""

@@ -9,6 +9,7 @@ from tstar_amd import yolo_world as Y
 
 @pytest.mark.parametrize("scale,channels,embed,heads", [("l", [256, 512, 512], [128, 256, 256], [4, 8, 8]),
                                                         ("x", [320, 640, 640], [160, 320, 320], [5, 10, 10]),
+                                                        ("xl", [384, 768, 768], [192, 384, 384], [6, 12, 12]),
                                                         ("s", [128, 256, 512], [64, 128, 256], [2, 4, 8])])
 def test_architecture_tables(scale, channels, embed, heads):
     A = Y.arch(scale)
@@ -17,6 +18,18 @@ def test_architecture_tables(scale, channels, embed, heads):
     assert A["reg_ch"] == max(16, channels[0] // 4, 64) and A["cls_ch"] == max(channels[0], 80)
     with pytest.raises(ValueError, match="unknown YOLO-World scale"):
         Y.arch("xxl")
+
+
+def test_scale_mismatch_is_reported_by_name():
+    """the reference wires the XL config (widen 1.5: 96-channel stem); building it as another scale names the
+    first tensor that does not fit instead of dying in a bare assert."""
+    A = Y.arch("xl")
+    assert A["stem"] == 96 and [s["cout"] for s in A["stages"]] == [192, 384, 768, 768]
+    sd = Y.synthetic_state_dict(0, "s")
+    with pytest.raises(ValueError, match=r"backbone\.image_model\.stem.*YOLO-World-v2-M"):
+        Y.build_program(sd, "m")
+    prog = Y.build_program(Y.synthetic_state_dict(0, "xl"), "xl")
+    assert prog["ops"].shape[0] > 60
 
 
 def test_layer_program_is_well_formed():

@@ -57,6 +57,7 @@ SIGNATURES = {
     "tstar_searcher_set_scores": (_i, [_vp, _vp, _vp, _i, _vp]),
     "tstar_searcher_read_state": (_i, [_vp, _vp, _vp]),
     "tstar_searcher_read": (_i, [_vp, _i, _vp, _vp]),
+    "tstar_comm_available": (_i, []),
     "tstar_comm_unique_id": (_i, [_vp]),
     "tstar_comm_create": (_i, [C.POINTER(_vp), _vp, _i, _i]),
     "tstar_comm_destroy": (_i, [_vp]),

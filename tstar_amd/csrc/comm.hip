@@ -77,6 +77,8 @@ struct tstar_comm {
 
 extern "C" {
 
+int tstar_comm_available(void) { return load_rccl(); }
+
 int tstar_comm_unique_id(void* h_id) {
     TSTAR_REQUIRE(h_id, "tstar_comm_unique_id: null argument");
     static_assert(sizeof(ncclUniqueId) == TSTAR_COMM_ID_BYTES, "TSTAR_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");

@@ -1094,6 +1094,11 @@ __global__ __launch_bounds__(1024) void sort_nms_kernel(unsigned long long* __re
                         k_box[kept][0] = x0; k_box[kept][1] = y0; k_box[kept][2] = x1; k_box[kept][3] = y1;
                         k_area[kept] = area; k_id[kept] = id; k_score[kept] = sc;
                     }
+                    // lane 0's survivor must be visible to every lane's LDS reads of the next candidate: a wavefront-scope
+                    // release fence + wave barrier pins the order for the compiler too (no load may be hoisted above it)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     ++kept;
                 }
             }

@@ -207,11 +207,11 @@ class OWLInterface(HeuristicInterface):
 
 
 def _yolo_scale_from_config(config_path: Optional[str]) -> str:
-    """'yolo_world_v2_xl_vlpan_...' -> 'x' (the reference wires the XL config, TStarFramework.py:181); BASELINE configs[3]
-    names the L model, which is the default when the name says nothing."""
+    """'yolo_world_v2_xl_vlpan_...' -> 'xl' (the config the reference wires, TStarFramework.py:181: the yolov8_x base scaled
+    "from X to XL", widen 1.5); BASELINE configs[3] names the L model, which is the default when the name says nothing."""
     import re
     m = re.search(r"yolo_world(?:_v2)?_(s|m|l|xl|x)_", os.path.basename(str(config_path or "")))
-    return {"xl": "x"}.get(m.group(1), m.group(1)) if m else "l"
+    return m.group(1) if m else "l"
 
 
 class YoloWorldInterface(HeuristicInterface):
@@ -241,7 +241,9 @@ class YoloWorldInterface(HeuristicInterface):
         if dev.index is not None:
             torch.cuda.set_device(dev.index)
         if state_dict is None and checkpoint_path and os.path.isfile(checkpoint_path):
-            ck = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+            # tensors only: the mmengine checkpoint's meta / optimizer objects are never needed, so nothing is unpickled
+            # beyond what torch's safe loader admits
+            ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
             ck = ck.get("state_dict", ck)
             state_dict = {k: v.float().numpy() for k, v in ck.items() if hasattr(v, "numpy")}
             self.weights_source = checkpoint_path

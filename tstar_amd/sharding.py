@@ -30,6 +30,16 @@ def _tstar_comm(world: int, rank: int):
     import torch.distributed as dist
     from . import _lib
     lib = _lib.load()
+    # every rank binds RCCL locally FIRST and the outcome is MIN-reduced: ncclCommInitRank is collective, so a rank that
+    # cannot load the library must be known before any rank enters it (the others would block inside it forever)
+    have = 1 if lib.tstar_comm_available() == 0 else 0
+    if not have:
+        print(f"tstar_amd[rank {rank}]: {lib.tstar_last_error().decode()}; gathering through torch.distributed", file=sys.stderr)
+    pre = torch.tensor([have], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+    if int(pre.item()) != 1:
+        _COMM = False
+        return None
     idbuf = C.create_string_buffer(128)
     box = [None]
     if rank == 0:

@@ -217,6 +217,8 @@ def load_y4m(path: str, device: str = "cuda", chunk: int = 64) -> FrameStore:
     from . import _lib
     hd = parse_y4m_header(path)
     w, h, fb = hd["w"], hd["h"], hd["frame_bytes"]
+    if (w * h) % 64:          # before any store / pinned buffer is allocated (tstar_i420_to_nv12 moves 64-byte units)
+        raise ValueError(f"Cannot open video file: {path} ({w}x{h}: the device repack needs W*H to be a multiple of 64)")
     n_sec = int(hd["n_frames"] / hd["fps"])
     if n_sec < 1:
         raise ValueError(f"Cannot open video file: {path} (shorter than one second)")
@@ -236,7 +238,10 @@ def load_y4m(path: str, device: str = "cuda", chunk: int = 64) -> FrameStore:
             idx = want[s0:s0 + chunk]
             host = pinned[b].numpy()
             for j, fi in enumerate(idx):
-                f.seek(hd["data_offset"] + fi * stride + hd["frame_header_bytes"])
+                f.seek(hd["data_offset"] + fi * stride)
+                if f.read(hd["frame_header_bytes"])[:5] != b"FRAME":       # per-frame parameters would shift every later frame
+                    raise ValueError(f"Cannot open video file: {path} (no FRAME marker where frame {fi} should start: "
+                                     f"frame headers of varying length are not supported)")
                 got = f.readinto(memoryview(host[j]))
                 if got != fb:
                     raise ValueError(f"Cannot open video file: {path} (truncated at frame {fi})")

@@ -37,8 +37,10 @@ BN_EPS = 1e-3                       # mmyolo norm_cfg: BN eps 0.001, momentum 0.
 STRIDES = (8, 16, 32)
 NUM_TRAINING_CLASSES = 80           # head_module.num_classes of the pretrain configs (sizes the cls tower)
 
-# scale -> (deepen, widen, last_stage_out_channels)   (mmyolo yolov8_{s,m,l,x}; YOLO-World keeps them)
-SCALES = {"s": (0.33, 0.5, 1024), "m": (0.67, 0.75, 768), "l": (1.0, 1.0, 512), "x": (1.0, 1.25, 512)}
+# scale -> (deepen, widen, last_stage_out_channels)   (mmyolo yolov8_{s,m,l,x}; YOLO-World keeps them).  "xl" is the
+# published yolo_world_v2_xl config -- the one the reference wires (TStarFramework.py:181-182) -- which scales the
+# yolov8_x base "from X to XL": deepen 1.0, widen 1.5 (96-channel stem, 192/384/768/768 stages, 6/12/12 attention heads)
+SCALES = {"s": (0.33, 0.5, 1024), "m": (0.67, 0.75, 768), "l": (1.0, 1.0, 512), "x": (1.0, 1.25, 512), "xl": (1.0, 1.5, 512)}
 
 # op codes of the layer program (mirrored in csrc/yolo.hip)
 OP_CONV, OP_POOL5, OP_UPCOPY, OP_ATTN = 0, 1, 2, 3
@@ -146,8 +148,9 @@ def synthetic_state_dict(seed: int = 0, scale: str = "l") -> "OrderedDict[str, n
 
 # ------------------------------------------------------------------------------------------ layer program
 class _Builder:
-    def __init__(self, sd):
+    def __init__(self, sd, A=None):
         self.sd = sd
+        self.A = A or {"scale": "?"}
         self.blob: List[np.ndarray] = []
         self.n = 0
         self.ops: List[List[int]] = []
@@ -170,6 +173,9 @@ class _Builder:
 
     def folded(self, name):
         """ConvModule -> (weight [Cout][kh][kw][Cin], bias [Cout]) with the eval-mode BatchNorm folded in float64."""
+        if name + ".conv.weight" not in self.sd:
+            raise ValueError(f"YOLO-World state dict has no tensor {name}.conv.weight: not a YOLO-World-v2-{self.A['scale'].upper()} "
+                             f"model (wrong scale= / config name?)")
         w = np.asarray(self.sd[name + ".conv.weight"], dtype=np.float64)
         g, b = np.asarray(self.sd[name + ".bn.weight"], np.float64), np.asarray(self.sd[name + ".bn.bias"], np.float64)
         m, v = np.asarray(self.sd[name + ".bn.running_mean"], np.float64), np.asarray(self.sd[name + ".bn.running_var"], np.float64)
@@ -186,8 +192,14 @@ class _Builder:
         cout, ks, _, cin = w.shape
         H, W, _ = self.bufs[src]
         Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (W + 2 * (ks // 2) - ks) // stride + 1
-        assert self.bufs[dst][:2] == (Ho, Wo), (name, self.bufs[dst], Ho, Wo)
-        assert src_off + cin <= self.bufs[src][2] and dst_off + cout <= self.bufs[dst][2], name
+        what = name or "raw conv"
+        if self.bufs[dst][:2] != (Ho, Wo):
+            raise ValueError(f"YOLO-World layer {what}: output map {Ho}x{Wo} does not fit its buffer {self.bufs[dst][0]}x{self.bufs[dst][1]}")
+        if src_off + cin > self.bufs[src][2] or dst_off + cout > self.bufs[dst][2]:
+            raise ValueError(
+                f"YOLO-World layer {what}: weight {tuple(w.shape[i] for i in (0, 3, 1, 2))} (Cout, Cin, k, k) expects {cin} input channels at "
+                f"offset {src_off} of a {self.bufs[src][2]}-channel buffer and writes {cout} at offset {dst_off} of a {self.bufs[dst][2]}-channel "
+                f"buffer: the state dict is not a YOLO-World-v2-{self.A['scale'].upper()} model (wrong scale= / config name?)")
         w_off = self.put(w)
         b_off = self.put(b) if b is not None else -1
         self.ops.append([OP_CONV, src, src_off, cin, dst, dst_off, cout, ks, stride, act, w_off, b_off, mode, aux, aux_off])
@@ -228,9 +240,17 @@ class _Builder:
 def build_program(state_dict, scale: str = "l") -> Dict:
     """-> dict(blob f32, ops int32 [n, OP_WORDS], bufs int32 [m, 3], guides int32 [a, 5], levels int32 [3, 8], arch)."""
     A = arch(scale)
-    B = _Builder(state_dict)
+    B = _Builder(state_dict, A)
     S = IMG_SIZE
     b = "backbone.image_model."
+    # the widths of the stem and of every stage's down-sampling conv identify the scale: name the first one that differs
+    # (a narrower model would otherwise fit silently inside the wider model's buffers)
+    want = [(b + "stem", A["stem"], 3)] + [(f"{b}stage{i}.0", st["cout"], st["cin"]) for i, st in enumerate(A["stages"], start=1)]
+    for nm, cout, cin in want:
+        t = state_dict.get(nm + ".conv.weight")
+        if t is None or tuple(np.shape(t)[:2]) != (cout, cin):
+            raise ValueError(f"YOLO-World tensor {nm}.conv.weight: expected (Cout, Cin) = ({cout}, {cin}) for YOLO-World-v2-{scale.upper()} "
+                             f"(widen {A['widen']}), got {None if t is None else tuple(np.shape(t))}: wrong scale= / config name for this checkpoint?")
     x = B.buf(S, S, 3)
     cur = B.buf(S // 2, S // 2, A["stem"])
     B.conv(b + "stem", x, 0, cur, 0, stride=2)
