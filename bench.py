@@ -460,6 +460,15 @@ def main():
     # time every 5th GEMM / attention launch with HIP event pairs (5 is co-prime with the 4-GEMM layer
     # pattern and the 52-GEMM forward, so every shape is sampled evenly); timing all of them costs 2.2 %
     _lib.check(lib.tstar_prof_enable(0 if os.environ.get('TSTAR_BENCH_NO_PROF') else PROF_STRIDE))
+
+    def stamp(which):
+        """Mark one end of the timed region for trace tools: an empty marker kernel on the launch stream (the window on the
+        GPU's own timeline, tools/rocpd_window.py) plus the host clocks a profiler may use for its timestamps."""
+        _lib.check(lib.tstar_prof_mark(which, _lib.stream_ptr()))
+        return {f"t{which}_realtime_ns": time.time_ns(), f"t{which}_monotonic_ns": time.monotonic_ns(),
+                f"t{which}_boottime_ns": time.clock_gettime_ns(time.CLOCK_BOOTTIME)}
+
+    timed_region = stamp(0)
     t0 = time.perf_counter()
     res = run_many(items)
     frames = sum(r[0].frames_scored for r in res)
@@ -470,8 +479,12 @@ def main():
     latency = sum(r[2] for r in res) / max(len(res), 1)
     # RCCL all-gather of the keyframe indices (N > 1), rows back in item order
     all_keys = gather_keyframes(keys, world, pad_to=(n_items_total + world - 1) // world)
+    from tstar_amd import sharding as _sh
+    collective_path = _sh.LAST_GATHER_PATH        # which way the timed gather went (RCCL through the C ABI on a GPU job)
     if world > 1:
         all_keys = interleave_by_item(all_keys, n_items_total, world)
+    torch.cuda.synchronize()
+    timed_region.update(stamp(1))
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(frames), float(images)], dtype=torch.float64, device=cdev)
@@ -488,6 +501,8 @@ def main():
     _lib.check(lib.tstar_prof_read(0, C.byref(n_l), C.byref(ms), C.byref(fl)))
     if args.heuristic == "yolo":                  # dominant kernels of the YOLO-World backend: the VALU convolutions (category 2)
         _lib.check(lib.tstar_prof_read(2, C.byref(n_l), C.byref(ms), C.byref(fl)))
+    by = C.c_double(0)
+    _lib.check(lib.tstar_prof_read_bytes(2 if args.heuristic == "yolo" else 0, C.byref(by)))
     a_l, a_ms, a_fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
     _lib.check(lib.tstar_prof_read(1, C.byref(a_l), C.byref(a_ms), C.byref(a_fl)))
     _lib.check(lib.tstar_prof_enable(0))
@@ -496,7 +511,7 @@ def main():
     # timed process, so the per-launch figure measured with `tools/rocpd_traffic.py` is read from the
     # committed summary (profiles/); None if it has not been collected.
     traffic, traffic_src = None, None
-    for tag in ("r02", "r01"):                     # the newest collection (tools/collect_profiles.sh) wins
+    for tag in ("r03", "r02", "r01"):              # the newest collection (tools/collect_profiles.sh) wins
         tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_gemm_traffic.json")
         if os.path.isfile(tp):
             try:
@@ -512,12 +527,14 @@ def main():
     if args.heuristic == "yolo":
         gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel + conv_sw_kernel (implicit-GEMM convolutions, v_pk_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r02_yolo_pmc_conv_traffic.json")     # tools/collect_yolo_profiles.sh (PMC passes of this command)
-        if os.path.isfile(tp):
-            try:
-                traffic, traffic_src = json.load(open(tp))["bytes_per_launch_corrected"], "profiles/r02_yolo_pmc_conv_traffic.json"
-            except Exception:
-                pass
+        for tag in ("r03", "r02"):                # tools/collect_yolo_profiles.sh (PMC passes of this command)
+            tp = os.path.join(ROOT, "profiles", f"{tag}_yolo_pmc_conv_traffic.json")
+            if os.path.isfile(tp):
+                try:
+                    traffic, traffic_src = json.load(open(tp))["bytes_per_launch_corrected"], f"profiles/{tag}_yolo_pmc_conv_traffic.json"
+                    break
+                except Exception:
+                    pass
     elif args.weights in ("bf16", "f32_split"):
         gemm_kernel, peak, exec_mult = f"gemm_f32_kernel<WMODE={1 if args.weights == 'bf16' else 2}> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
     else:
@@ -552,7 +569,7 @@ def main():
                       "f32_split": "f32 operands as 2 bf16 terms each (16 significand bits), 3 bf16 MFMA products, f32 accumulate"}[args.weights],
             "data": "synthetic",
             "config": {
-                "collective_backend": (backend if world > 1 else None),
+                "collective_backend": (backend if world > 1 else None), "collective_path": collective_path,
                 "workload": f"{wl_name}: {wl_what}; {det_name}, grid {g}x{g} = "
                             f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
                 "workload_kind": workload, "items_total": n_items_total,
@@ -560,8 +577,11 @@ def main():
                 "mean_search_latency_sec": latency, "single_search_alone_latency_sec": solo_latency,
                 "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,
                 "detector_images_per_video": images / args.steps, "max_batch": args.max_batch,
-                "keyframes_rank0_step0": keys[0], "gathered_keyframe_rows": len(all_keys),
+                "keyframes_rank0_step0": keys[0], "gathered_keyframe_rows": len(all_keys), "gathered_keyframes": all_keys,
                 "keyframes_verified": verified, "keyframes_verification": verify_detail,
+                # both ends of the timed region: marker kernels prof_mark_begin_kernel / prof_mark_end_kernel were enqueued on
+                # the launch stream at these instants (a kernel trace is cut between them: tools/rocpd_window.py)
+                "timed_region": timed_region,
             },
             "roofline": {
                 "kernel": gemm_kernel, "bound": bound, "achieved": achieved * exec_mult,
@@ -571,6 +591,10 @@ def main():
                 "traffic_source": traffic_src,
                 "launches_timed": n_l.value, "timed_every_nth_launch": PROF_STRIDE, "avg_launch_ms": ms.value / max(n_l.value, 1),
                 "avg_launch_gflop": fl.value / max(n_l.value, 1) / 1e9,
+                # every operand read once, the result written once (GEMM: A + W + C + residual + bias rows; conv: input
+                # channels + output channels + weights + fused residual / gate), averaged over the same sampled launches
+                "algorithmic_bytes_per_launch": by.value / max(n_l.value, 1),
+                "traffic_over_algorithmic": (traffic / (by.value / n_l.value)) if traffic and by.value > 0 and n_l.value else None,
                 "time_share_of_step": ms.value * PROF_STRIDE * 1e-3 / dt / max(conc, 1),
                 "attention_f32_kernel": {"achieved": (a_fl.value / (a_ms.value * 1e-3) / 1e12) if a_ms.value > 0 else 0.0,
                                          "launches_timed": a_l.value, "time_share_of_step": a_ms.value * PROF_STRIDE * 1e-3 / dt / max(conc, 1)},

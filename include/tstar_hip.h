@@ -297,6 +297,11 @@ int tstar_attention_split(const float* d_qkv, float* d_out, int B, int T, int he
  * read() synchronises the recorded events and returns launches / total ms / total algorithmic flops. */
 int tstar_prof_enable(int on);
 int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops);
+/* algorithmic HBM bytes of the launches tstar_prof_read counted (operands read once, results written once) */
+int tstar_prof_read_bytes(int category, double* total_bytes);
+/* trace markers: enqueue an empty kernel named prof_mark_begin_kernel (which = 0) / prof_mark_end_kernel (1) on `stream`,
+ * so that a rocprofv3 kernel trace can be cut to the bracketed region on the GPU's own timeline */
+int tstar_prof_mark(int which, void* stream);
 
 #ifdef __cplusplus
 }

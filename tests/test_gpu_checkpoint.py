@@ -1,0 +1,82 @@
+"""Real-checkpoint path on the GPU: a checkpoint DIRECTORY in HF's own layout -- HF-initialised
+``OwlViTForObjectDetection(OwlViTConfig())`` saved with ``save_pretrained`` + CLIP BPE vocabulary files -- goes through
+``OWLInterface(model_name_or_path=dir)`` exactly as the reference constructs it (TStarFramework.py:176 ->
+interface_heuristic.py:207-210): ``find_pretrained`` -> safetensors -> blob -> HIP towers, queries through the real
+CLIP-BPE branch of tstar_amd/tokenizer.py.  Checked against HF's own forward on the same files (CPU, f32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ckpt(tmp_path_factory):
+    import hf_checkpoint_util as H
+    from transformers import CLIPTokenizer
+    d = str(tmp_path_factory.mktemp("owlvit_ckpt"))
+    m = H.make_checkpoint_dir(d, seed=1)
+    return d, m, CLIPTokenizer.from_pretrained(d, local_files_only=True)
+
+
+def test_checkpoint_directory_through_the_gpu_path(ckpt):
+    import hf_checkpoint_util as H
+    from oracle.clip_bpe_ref import ClipBpe
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_frames_numpy, synthetic_video
+    d, m, tok = ckpt
+    h = OWLInterface(model_name_or_path=d, max_batch=4)                    # the reference's constructor call; no synthetic_seed
+    assert h.weights_source == os.path.join(d, "model.safetensors") and not h.allow_standin_tokenizer
+    targets, cues = ["couch"], ["tv", "remote control", "dog's leash!"]
+    h.reparameterize_object_list(targets, cues)
+    names = [t[0] for t in h.texts]
+    assert names == ["couch", "tv", "remote control", "dog's leash!", " "]
+    want = tok(names, padding="max_length", max_length=16, truncation=True, return_tensors="np")
+    assert np.array_equal(h._ids, want["input_ids"]) and np.array_equal(h._am, want["attention_mask"])
+    bpe = ClipBpe(os.path.join(d, "vocab.json"), os.path.join(d, "merges.txt"))
+    assert np.array_equal(h._ids, bpe.encode_queries(names)[0])             # ... and the restated BPE agrees with both
+    assert h._ids[3, 5] == 0 and h._am[3, 5] == 1                           # the literal "!" is HF's pad-token quirk: id 0, attended
+    for k, (H_, W_) in enumerate([(285, 600), (380, 800)]):
+        img = synthetic_frames_numpy([7 + k], 40, 360, 640, seed=5)[0]
+        from oracle import resize_ref as R
+        img = R.cv_bilinear_resize(img, W_, H_)
+        ref = H.hf_detect(m, tok, img, names)
+        if k == 0:
+            qe = h.scorer.get_query_embeds()
+            assert np.abs(qe - ref["text_embeds"]).max() < 1e-5             # D6: text tower on the real BPE ids
+        det = h.inference_detector([img])[0]
+        r = h.scorer.score(torch.from_numpy(img).cuda().unsqueeze(0), 1, 1)
+        dense = r.scores[0].cpu().numpy()
+        err = float(np.abs(dense - ref["dense_scores"]).max())
+        assert err < 1e-3, err                                               # the north-star contract; observed ~1e-6
+        assert 0.05 < ref["dense_scores"].min() and ref["dense_scores"].max() < 0.95       # not a saturated comparison
+        assert len(det) == len(ref["scores"]) == 576                         # threshold 0.005: every patch kept, patch order
+        assert np.abs(det.confidence - ref["scores"]).max() < 1e-3
+        assert np.abs(det.xyxy - ref["xyxy"]).max() < 1e-2                   # pixels of the passed image
+        top2 = np.sort(ref["logits"], axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-3                             # arg-max is only defined up to the logit tolerance
+        assert clear.mean() > 0.9 and np.array_equal(det.class_id[clear], ref["labels"][clear])
+        print(f"checkpoint dir, {H_}x{W_}: max |score - HF| = {err:.2e}")
+    # a search over a short video runs on the same heuristic (queries re-encoded through the real BPE per question)
+    store = synthetic_video(64, seed=2)
+    s = TStarSearcher(store, h, targets, cues[:2], search_nframes=4, image_grid_shape=(2, 2), search_budget=0.5,
+                      confidence_threshold=0.6, rng=np.random.RandomState(3), keep_visual_history=False)
+    frames, ts = s.search()
+    assert len(ts) == 4 and frames.shape == (4, 360, 640, 3)
+
+
+def test_checkpoint_without_vocabulary_refuses_made_up_ids(ckpt, tmp_path):
+    """A real checkpoint with NO vocabulary next to it must not be fed stand-in ids."""
+    import shutil
+    from tstar_amd.interface_heuristic import OWLInterface
+    d, _, _ = ckpt
+    bare = tmp_path / "bare"
+    bare.mkdir()
+    for f in ("model.safetensors", "config.json"):
+        shutil.copy(os.path.join(d, f), bare / f)
+    h = OWLInterface(model_name_or_path=str(bare), max_batch=1)
+    with pytest.raises(RuntimeError, match="no CLIP tokenizer files"):
+        h.reparameterize_object_list(["couch"], [])

@@ -66,3 +66,103 @@ def test_dataset_driver_equals_one_by_one_searches(tmp_path):
         _, ts = s.search()
         assert [float(t) for t in ts] == item["keyframe_timestamps"], i
         assert s.P_history[-1] == item["keyframe_distribution"]
+
+
+def test_configs2_haystack32_full_size():
+    """BASELINE configs[2] at its own size on the one GPU of the test box: 32 distinct 3600-frame procedural videos
+    (80 GB of HBM), 4 cycled questions, lock-step groups of 4, through run_sharded at world 1 (the N-rank driver of
+    run_TStar_onDataset.py:195-211 sharded; item i -> rank i % world).  Every item's keyframes / score distribution / P
+    must equal its one-by-one search (per-item sampler seed: results independent of grouping and rank count), and two
+    items with different questions are teacher-forced through the CPU oracle searcher (oracle/replay.py): sampled
+    seconds, score history and keyframes bit-exact."""
+    import bench as B
+    from oracle import replay
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.lockstep import search_lockstep
+    from tstar_amd.sharding import run_sharded
+    from tstar_amd.video import synthetic_video
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2 ** 30:
+        pytest.skip("needs 100 GB of free HBM for 32 resident 3600-frame videos")
+    n_items, g, K = 32, 16, 8
+    h = OWLInterface(synthetic_seed=0, max_batch=256)
+    items = [dict(id=i, store=synthetic_video(B.N_FRAMES, B.FRAME_H, B.FRAME_W, seed=1000 + i), targets=B.QUESTIONS[i % 4][0],
+                  cues=B.QUESTIONS[i % 4][1], seed=2025 + i) for i in range(n_items)]
+    grouped = {}
+
+    def group(ids):
+        ss = [B.make_searcher(h, items[i], g, K) for i in ids]
+        res = search_lockstep(ss)
+        for i, s_, r in zip(ids, ss, res):
+            grouped[i] = (s_, [int(t) for t in r[1]])
+        return [grouped[i][1] for i in ids]
+
+    rows = run_sharded(n_items, None, 1, 0, search_group=group, group_size=4)
+    assert len(rows) == n_items and all(len(r) == K and r == sorted(r) for r in rows)
+    assert len({tuple(r) for r in rows}) > 20                   # distinct videos / seeds: not one answer repeated
+    replayed = 0
+    for i in range(n_items):
+        it = items[i]
+        teacher = i in (1, 6)                                   # questions 1 and 2 (one target + cues / one target + one cue)
+        rec = replay.Recorder(h, keep_images=False) if teacher else None
+        try:
+            s = B.make_searcher(h, it, g, K)
+            log = []
+            orig = s.sample_frames
+            s.sample_frames = lambda num, _o=orig, _l=log: (lambda r: (_l.append(list(r[0])), r)[1])(_o(num))
+            _, ts = s.search()
+        finally:
+            if rec:
+                rec.restore()
+        solo = [int(t) for t in ts]
+        sg = grouped[i][0]
+        assert solo == rows[i], (i, solo, rows[i])
+        assert np.array_equal(s.score_distribution, sg.score_distribution) and s.P_history[-1] == sg.P_history[-1], i
+        assert s.frames_scored == sg.frames_scored and s.iterations == sg.iterations
+        if teacher:
+            ref, ts_ref = replay.replay_through_oracle(rec.calls, h.texts, it["targets"], it["cues"], s.total_frame_num, g, K, 1000, 0.6,
+                                                       it["seed"])
+            assert [int(t) for t in ts_ref] == solo, i
+            assert [x["secs"] for x in ref.trace] == log, i
+            assert np.array_equal(s.score_distribution, ref.score), i
+            replayed += 1
+    assert replayed == 2
+    del items, grouped
+    torch.cuda.empty_cache()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _bench_line(cmd, env):
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_equals_one_rank():
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one process per rank), with two ranks
+    sharing the box's one GPU over gloo (TSTAR_BENCH_BACKEND=gloo; on an 8-GPU node the same code runs over RCCL):
+    item i on rank i % 2, one all-gather of the keyframe rows inside the timed region.  The gathered rows must be the
+    1-rank run's rows for the same 4 items (sampler seeds are a function of the item id only)."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-grid4", "--no-verify", "--max-batch", "64"]
+    env = dict(os.environ, TSTAR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    two = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + common, env)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["workload_kind"] == "haystack"
+    assert two["config"]["items_total"] == 4 and two["config"]["gathered_keyframe_rows"] == 4
+    assert two["config"]["collective_backend"] == "gloo" and "gloo" in two["config"]["collective_path"]
+    assert two["value"] > 0 and two["roofline"]["launches_timed"] > 0 and two["roofline"]["algorithmic_bytes_per_launch"] > 0
+    one = _bench_line([sys.executable, "bench.py", "--workload", "haystack", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-grid4",
+                       "--no-verify", "--max-batch", "64"], dict(os.environ))
+    assert one["n_gpus"] == 1 and one["config"]["gathered_keyframe_rows"] == 4
+    assert one["config"]["gathered_keyframes"] == two["config"]["gathered_keyframes"]
+    assert all(len(r) == 8 for r in one["config"]["gathered_keyframes"])
+    assert "t0_boottime_ns" in one["config"]["timed_region"] and one["config"]["timed_region"]["t1_monotonic_ns"] > one["config"]["timed_region"]["t0_monotonic_ns"]

@@ -150,6 +150,17 @@ assert shard_items(10, world, rank) == list(range(rank, 10, world))
 # fewer items than ranks: ranks 2 and 3 own nothing
 res = run_sharded(2, search, world, rank)
 assert res == [search(0), search(1)], res
+# lock-step groups of 2 within each rank's shard (what configs[2] runs per GPU): same gathered rows, groups seen in shard order
+seen = []
+def group(ids):
+    seen.append(list(ids))
+    return [search(i) for i in ids]
+res = run_sharded(10, None, world, rank, search_group=group, group_size=2)
+assert res == [search(i) for i in range(10)], res
+mine = shard_items(10, world, rank)
+assert seen == [mine[k:k + 2] for k in range(0, len(mine), 2)], seen
+from tstar_amd import sharding
+assert "gloo" in sharding.LAST_GATHER_PATH and "4 ranks" in sharding.LAST_GATHER_PATH
 dist.destroy_process_group()
 print("ok")
 '''
@@ -367,3 +378,40 @@ def test_y4m_header_round_trip_and_rejection(tmp_path):
         p.write_bytes(blob)
         with pytest.raises(ValueError, match="Cannot open video file"):
             parse_y4m_header(str(p))
+
+
+def test_real_checkpoint_directory_host_side(tmp_path):
+    """D1 / D6 host side without a GPU: a checkpoint directory in HF's layout (HF-initialised model saved with
+    save_pretrained + CLIP vocabulary files, tests/hf_checkpoint_util.py) is found, loaded from safetensors and packed into
+    both tower blobs; queries take the real CLIP-BPE branch of tstar_amd/tokenizer.py: ids equal to transformers'
+    CLIPTokenizer on the same files and to the restated algorithm (oracle/clip_bpe_ref.py), including HF's "!" = pad-id
+    quirk, unicode, contractions and truncation to 16 with EOS kept."""
+    import hf_checkpoint_util as H
+    from oracle.clip_bpe_ref import ClipBpe
+    from tstar_amd import weights as W
+    from tstar_amd.tokenizer import encode_queries
+    from transformers import CLIPTokenizer
+    d = str(tmp_path / "ckpt")
+    m = H.make_checkpoint_dir(d, seed=0)
+    ck = W.find_pretrained(d)
+    assert ck == os.path.join(d, "model.safetensors")
+    sd = W.load_safetensors_state_dict(ck)
+    bv, bt = W.pack_blob(sd, W.vision_spec()), W.pack_blob(sd, W.text_spec())
+    wv = W.unpack_blob(bv, W.vision_spec())
+    hf = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    assert np.array_equal(wv["box_bias"], m.box_bias.numpy())                  # the non-persistent buffer is recomputed identically
+    k = "owlvit.vision_model.encoder.layers.3.mlp.fc1.weight"
+    assert any(np.array_equal(v.reshape(-1), hf[k].reshape(-1)) for v in wv.values() if v.size == hf[k].size)
+    names = ["couch", "tv", "park bench", " ", "Remote-Control 42!", "a photo of the dog's leash", "wow!! a!b  CAT",
+             "the cat the dog the car the road the mug the desk the tv the chair the couch", "na\u00efve caf\u00e9 \u21165 \u00bd", "it's o'clock we're"]
+    ids, am = encode_queries([[n] for n in names], d, allow_standin=False)
+    tok = CLIPTokenizer.from_pretrained(d, local_files_only=True)
+    want = tok(names, padding="max_length", max_length=16, truncation=True, return_tensors="np")
+    assert np.array_equal(ids, want["input_ids"]) and np.array_equal(am, want["attention_mask"])
+    bpe = ClipBpe(os.path.join(d, "vocab.json"), os.path.join(d, "merges.txt"))
+    ids2, am2 = bpe.encode_queries(names)
+    assert np.array_equal(ids, ids2) and np.array_equal(am, am2)
+    assert ids[0, 0] == 49406 and ids[0, 2] == 49407 and ids[7, 15] == 49407 and ids[4, -1] == 0 and (ids[3, :3] == [49406, 49407, 0]).all()
+    # a different directory without vocabulary files does not inherit this one's tokenizer (per-path cache)
+    with pytest.raises(RuntimeError, match="no CLIP tokenizer files"):
+        encode_queries([["couch"]], str(tmp_path / "nowhere"), allow_standin=False)

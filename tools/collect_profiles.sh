@@ -17,7 +17,6 @@ PY="python $ROOT/bench.py"
 : > "$OUT/bench.err"
 $PY --steps 16 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights f32_split --no-cpu-baseline > "$OUT/${TAG}_bench_f32_split.json" 2>> "$OUT/bench.err"
 $PY --steps 4 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --workload haystack --no-cpu-baseline > "$OUT/${TAG}_bench_haystack_1gpu.json" 2>> "$OUT/bench.err"
@@ -27,15 +26,21 @@ $PY --workload haystack32 --no-cpu-baseline > "$OUT/${TAG}_bench_haystack32_1gpu
 bash $ROOT/tools/collect_yolo_profiles.sh $TAG
 cd /tmp
 
-# 2. kernel trace of the bench command
+# 2. kernel trace of the bench command (the driver's default flags: the untimed post-timer legs -- keyframe
+#    verification, config.grid4 -- run too; the timed region is cut out of the trace at the marker kernels bench.py
+#    enqueues around it, tools/rocpd_window.py)
 rm -rf /tmp/prof_kt
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $PY --steps 8 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/rocprof_kt.err"
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
+BJ="$OUT/${TAG}_bench_under_rocprofv3.json"
 python $ROOT/tools/rocpd_stats.py "$DB" > "$OUT/${TAG}_rocprofv3_kernel_stats.md"
-WIN=$(python -c "import json; d=json.load(open('$OUT/${TAG}_bench_under_rocprofv3.json')); print(d['ms_per_step'] * d['steps'])")
-python $ROOT/tools/rocpd_stats.py "$DB" --window-ms "$WIN" > "$OUT/${TAG}_rocprofv3_kernel_stats_timed_region.md"
+# --check: the trace must reproduce the bench line's roofline leg (average GEMM launch within 3 %, dispatch count within 2 %)
+if ! python $ROOT/tools/rocpd_stats.py "$DB" --timed-region "$BJ" --check > "$OUT/${TAG}_rocprofv3_kernel_stats_timed_region.md"; then
+    echo "collect_profiles: the kernel trace does NOT reproduce roofline.avg_launch_ms / launches_timed -- see ${TAG}_rocprofv3_kernel_stats_timed_region.md" >&2
+    FAILED=1
+fi
 python $ROOT/tools/rocpd_shapes.py "$DB" > "$OUT/${TAG}_rocprofv3_kernel_shapes.md"
-python $ROOT/tools/rocpd_gaps.py "$DB" --window-ms "$WIN" > "$OUT/${TAG}_gpu_idle_gaps.txt"
+python $ROOT/tools/rocpd_gaps.py "$DB" --timed-region "$BJ" > "$OUT/${TAG}_gpu_idle_gaps.txt"
 
 # 3. counter passes (one counter set per run)
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES"; do
@@ -68,3 +73,4 @@ python $ROOT/tools/sweep_small_m.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_gem
 python $ROOT/tools/bench_kernels.py > "$OUT/${TAG}_kernel_microbench.log" 2>&1
 python $ROOT/tools/bench_ingest.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_ingest_bandwidth.log"
 ls -la "$OUT"
+exit ${FAILED:-0}

@@ -11,8 +11,8 @@ PY="python $ROOT/bench.py"
 rm -rf /tmp/prof_yolo
 rocprofv3 --kernel-trace --stats -d /tmp/prof_yolo -o kt -- $PY --heuristic yolo --steps 8 --warmup 1 --no-cpu-baseline --no-verify > "$OUT/${TAG}_bench_yolo_under_rocprofv3.json" 2> "$OUT/rocprof_yolo.err"
 DBY=$(find /tmp/prof_yolo -name '*.db' | head -1)
-WINY=$(python -c "import json; d=json.load(open('$OUT/${TAG}_bench_yolo_under_rocprofv3.json')); print(d['ms_per_step'] * d['steps'])")
-python $ROOT/tools/rocpd_stats.py "$DBY" --window-ms "$WINY" > "$OUT/${TAG}_yolo_rocprofv3_kernel_stats_timed_region.md"
+python $ROOT/tools/rocpd_stats.py "$DBY" --timed-region "$OUT/${TAG}_bench_yolo_under_rocprofv3.json" --check > "$OUT/${TAG}_yolo_rocprofv3_kernel_stats_timed_region.md" \
+    || echo "collect_yolo_profiles: the kernel trace does NOT reproduce the bench line's conv launch average / count" >&2
 rm -rf /tmp/prof_yolo2
 rocprofv3 --kernel-trace -d /tmp/prof_yolo2 -o kt -- python $ROOT/tools/yolo_forward_probe.py 32 > "$OUT/${TAG}_yolo_forward_probe.log" 2>&1
 python $ROOT/tools/rocpd_shapes.py "$(find /tmp/prof_yolo2 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_kernel_shapes_b32.md"

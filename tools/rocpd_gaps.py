@@ -1,29 +1,34 @@
 """GPU idle time between kernels in a rocprofv3 kernel trace (single stream): where the host is the bottleneck.
 
     python tools/rocpd_gaps.py <db> [fraction of the trace to keep, default 0.6]
-    python tools/rocpd_gaps.py <db> --window-ms 1569      # the last 1569 ms (= the bench's timed region)
+    python tools/rocpd_gaps.py <db> --timed-region [bench.json]     # the bench's timed region (marker kernels, tools/rocpd_window.py)
 """
+import os
 import re
-import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocpd_window import kernel_rows  # noqa: E402
 
 
 def short(name):
     return re.sub(r"\(.*$", "", name).replace("void ", "").replace("tstar::", "")[:60]
 
 
-c = sqlite3.connect(sys.argv[1])
-rows = c.execute("select name, start, end from kernels order by start").fetchall()
-# keep the last `frac` of the trace (the timed searches), default 60 %, or an explicit window
-t0, t1 = rows[0][1], max(r[2] for r in rows)
-if len(sys.argv) > 3 and sys.argv[2] == "--window-ms":
-    cut = t1 - float(sys.argv[3]) * 1e6
+a = sys.argv[1:]
+if "--timed-region" in a:
+    i = a.index("--timed-region")
+    bj = a[i + 1] if i + 1 < len(a) else None
+    rows, how, _ = kernel_rows(a[0], bj)
+    print(f"window: {how}")
 else:
-    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.6
+    rows, _, _ = kernel_rows(a[0], None, window_on=False)
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    frac = float(a[1]) if len(a) > 1 else 0.6
     cut = t1 - (t1 - t0) * frac
-rows = [r for r in rows if r[1] >= cut]
+    rows = [r for r in rows if r[1] >= cut]
 busy = sum(e - s for _, s, e in rows)
-span = rows[-1][2] - rows[0][1]
+span = max(r[2] for r in rows) - rows[0][1]
 gaps = []
 for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
     if s1 > e0:

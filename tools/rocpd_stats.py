@@ -1,15 +1,24 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average / share.
 
-    python tools/rocpd_stats.py gpurun_out/prof/bench_results.db > profiles/r01_kernel_stats.md
-    python tools/rocpd_stats.py <db> --window-ms 1569     # only the last 1569 ms of the trace (= the bench's
-                                                          # timed region: ms_per_step x steps of the traced run)
+    python tools/rocpd_stats.py <db>                                   # the whole trace
+    python tools/rocpd_stats.py <db> --timed-region [bench.json]       # only the bench's timed region: cut at the marker
+                                                                       # kernels bench.py enqueues around it (tools/rocpd_window.py;
+                                                                       # the JSON's host stamps are the fallback)
+    python tools/rocpd_stats.py <db> --timed-region bench.json --check # exit 1 unless the trace reproduces the JSON's roofline leg:
+                                                                       # |trace avg - roofline.avg_launch_ms| <= 3 % and the number of
+                                                                       # dominant-kernel dispatches = stride x launches_timed +- 2 %
 
-Ends with the aggregate over every gemm_f32* dispatch (the figure to compare with bench.py's
-roofline.avg_launch_ms, which is measured with HIP events inside the timed region).
+Ends with the aggregate over every dispatch of the dominant kernel family (gemm_f32*, or conv_* for the YOLO-World
+backend): the figure to compare with bench.py's roofline.avg_launch_ms, which is measured with HIP events inside the
+timed region.
 """
+import json
+import os
 import re
-import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocpd_window import kernel_rows  # noqa: E402
 
 
 def short(name: str) -> str:
@@ -18,12 +27,8 @@ def short(name: str) -> str:
     return name[:90]
 
 
-def main(path, window_ms=None):
-    c = sqlite3.connect(path)
-    rows = c.execute("select name, start, end from kernels").fetchall()
-    if window_ms is not None:
-        t_end = max(e for _, _, e in rows)
-        rows = [r for r in rows if r[1] >= t_end - window_ms * 1e6]
+def main(path, timed=False, bench_json=None, check=False):
+    rows, how, (lo, hi) = kernel_rows(path, bench_json, window_on=timed)
     agg = {}
     for name, s, e in rows:
         a = agg.setdefault(name, [0, 0])
@@ -31,25 +36,51 @@ def main(path, window_ms=None):
         a[1] += (e - s)
     total = sum(v[1] for v in agg.values())
     print(f"# rocprofv3 --kernel-trace --stats summary ({path.split('/')[-1]}"
-          + (f", last {window_ms:.0f} ms = the bench's timed region" if window_ms is not None else "") + ")\n")
+          + (f", the bench's timed region: window from {how}, {(hi - lo) / 1e6:.1f} ms" if timed and lo is not None else
+             (", " + how if timed else "")) + ")\n")
     print(f"total kernel time {total/1e6:.3f} ms over {len(rows)} dispatches\n")
     print("| kernel | calls | total ms | avg us | % |")
     print("|---|---:|---:|---:|---:|")
     for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{short(name)}` | {n} | {t/1e6:.3f} | {t/n/1e3:.1f} | {100*t/total:.2f} |")
 
-
-    gn = sum(n for name, (n, t) in agg.items() if "gemm_f32" in name)
-    gt = sum(t for name, (n, t) in agg.items() if "gemm_f32" in name)
+    bj = json.load(open(bench_json)) if bench_json and os.path.isfile(bench_json) else None
+    fam = ("conv_valu_kernel", "conv_sw_kernel", "conv_halo_kernel") if bj and bj.get("roofline", {}).get("bound") == "valu" else ("gemm_f32",)
+    gn = sum(n for name, (n, t) in agg.items() if any(f in name for f in fam))
+    gt = sum(t for name, (n, t) in agg.items() if any(f in name for f in fam))
+    ok = True
     if gn:
-        print(f"\nall `gemm_f32*` dispatches: {gn} calls, {gt / 1e6:.3f} ms, average {gt / gn / 1e6:.4f} ms "
+        print(f"\nall `{'* / '.join(fam)}*` dispatches: {gn} calls, {gt / 1e6:.3f} ms, average {gt / gn / 1e6:.4f} ms "
               f"({100 * gt / total:.1f} % of the kernel time)")
+    if bj and timed:
+        r = bj["roofline"]
+        want_n = r["launches_timed"] * r["timed_every_nth_launch"]
+        avg = gt / max(gn, 1) / 1e6
+        d_avg = abs(avg - r["avg_launch_ms"]) / r["avg_launch_ms"]
+        d_n = abs(gn - want_n) / max(want_n, 1)
+        steps = bj["steps"]
+        print(f"\nagainst the bench line of the same run: roofline.avg_launch_ms {r['avg_launch_ms']:.4f} (HIP events, every "
+              f"{r['timed_every_nth_launch']}th launch, {r['launches_timed']} sampled) vs {avg:.4f} from the trace: {100 * d_avg:.2f} % apart; "
+              f"dispatches {gn} vs {r['timed_every_nth_launch']} x {r['launches_timed']} = {want_n}: {100 * d_n:.2f} % apart; "
+              f"{gn / steps:.1f} dispatches per step; window {(hi - lo) / 1e6 if lo is not None else float('nan'):.1f} ms vs ms_per_step x steps = "
+              f"{bj['ms_per_step'] * steps:.1f} ms")
+        ok = d_avg <= 0.03 and d_n <= 0.02
+        print("CHECK " + ("passed" if ok else "FAILED") + " (|avg| <= 3 %, dispatch count <= 2 %)")
+    if check and not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":
-    w = None
-    if "--window-ms" in sys.argv:
-        i = sys.argv.index("--window-ms")
-        w = float(sys.argv[i + 1])
-        del sys.argv[i:i + 2]
-    main(sys.argv[1], w)
+    a = sys.argv[1:]
+    check = "--check" in a
+    if check:
+        a.remove("--check")
+    timed = "--timed-region" in a
+    bj = None
+    if timed:
+        i = a.index("--timed-region")
+        if i + 1 < len(a) and not a[i + 1].endswith(".db"):
+            bj = a[i + 1]
+            del a[i + 1]
+        del a[i]
+    main(a[0], timed, bj, check)

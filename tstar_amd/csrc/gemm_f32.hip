@@ -421,6 +421,13 @@ constexpr int lds_bytes(int bm, int bn) {
     return WMODE == 2 ? 2 * (2 * bm + 2 * bn) * 64 : WMODE == 1 ? 2 * (3 * bm + bn) * 64 : 2 * (bm + bn) * LDS_LD * 4;
 }
 
+// algorithmic HBM bytes of one launch: A and W read once, C written once, residual read once, bias / position rows
+static double gemm_algorithmic_bytes(const GemmArgs& g) {
+    const double wbytes = g.Wb ? (g.Wb2 ? 4.0 : 2.0) : 4.0;            // bf16 weights: one term; f32-split: two bf16 terms
+    return 4.0 * g.M * g.K + wbytes * g.N * g.K + 4.0 * g.M * g.N * (g.res ? 2.0 : 1.0) + (g.bias ? 4.0 * g.N : 0.0) +
+           (g.pos ? 4.0 * (g.patch_np + 1) * g.N : 0.0);
+}
+
 template <class CF, int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     constexpr int lds = lds_bytes<WMODE>(CF::BM, CF::BN);
@@ -428,7 +435,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     const int nwg = cdiv(g.M, CF::BM) * (g.N / CF::BN);
     const bool prof = prof_enabled();
-    if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K);
+    if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K, gemm_algorithmic_bytes(g));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, g);
     if (prof) prof_stop(PROF_GEMM, stream);
     TSTAR_HIP_CHECK(hipGetLastError());
@@ -443,7 +450,7 @@ static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
     const int nt = g.N / 128;
     const int nwg = (g.m_split / 128) * nt + cdiv(g.M - g.m_split, 64) * nt;
     const bool prof = prof_enabled();
-    if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K);
+    if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K, gemm_algorithmic_bytes(g));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, g);
     if (prof) prof_stop(PROF_GEMM, stream);
     TSTAR_HIP_CHECK(hipGetLastError());

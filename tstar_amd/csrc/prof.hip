@@ -7,8 +7,8 @@
 #include <vector>
 
 namespace tstar {
-struct Pair { hipEvent_t a, b; double work; };
-struct Cat { std::vector<Pair> pending; std::vector<Pair> pool; long launches = 0; double ms = 0, work = 0; };
+struct Pair { hipEvent_t a, b; double work, bytes; };
+struct Cat { std::vector<Pair> pending; std::vector<Pair> pool; long launches = 0; double ms = 0, work = 0, bytes = 0; };
 static Cat g_cat[PROF_NCAT];
 static bool g_on = false;
 static int g_stride = 1;            // time every g_stride-th launch of a category
@@ -23,14 +23,14 @@ static void drain(Cat& c) {
     for (Pair& p : c.pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            c.ms += ms; c.work += p.work; c.launches += 1;
+            c.ms += ms; c.work += p.work; c.bytes += p.bytes; c.launches += 1;
         }
         c.pool.push_back(p);
     }
     c.pending.clear();
 }
 
-void prof_start(int cat, hipStream_t s, double work) {
+void prof_start(int cat, hipStream_t s, double work, double bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
     t_last_b[cat] = nullptr;
     if ((g_seen[cat]++ % g_stride) != 0) return;          // not sampled: prof_stop sees no pending event
@@ -39,7 +39,7 @@ void prof_start(int cat, hipStream_t s, double work) {
     Pair p;
     if (!c.pool.empty()) { p = c.pool.back(); c.pool.pop_back(); }
     else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
-    p.work = work;
+    p.work = work; p.bytes = bytes;
     (void)hipEventRecord(p.a, s);
     c.pending.push_back(p);
     t_last_b[cat] = p.b;
@@ -49,6 +49,12 @@ void prof_stop(int cat, hipStream_t s) {
     if (t_last_b[cat]) (void)hipEventRecord(t_last_b[cat], s);      // the stop event of THIS thread's last start
     t_last_b[cat] = nullptr;
 }
+
+// Markers for kernel traces: two empty kernels with their own names.  A host brackets a region of interest with them
+// and the trace tools (tools/rocpd_window.py) cut the kernel table at [end of the last begin marker, start of the last
+// end marker] -- on the GPU's own timeline, independent of any host clock.
+__global__ void prof_mark_begin_kernel() {}
+__global__ void prof_mark_end_kernel() {}
 }  // namespace tstar
 
 using namespace tstar;
@@ -58,7 +64,7 @@ int tstar_prof_enable(int on) {
     g_on = on != 0;
     g_stride = on > 1 ? on : 1;
     for (int i = 0; i < PROF_NCAT; ++i) {
-        g_seen[i] = 0; drain(g_cat[i]); g_cat[i].launches = 0; g_cat[i].ms = 0; g_cat[i].work = 0; }
+        g_seen[i] = 0; drain(g_cat[i]); g_cat[i].launches = 0; g_cat[i].ms = 0; g_cat[i].work = 0; g_cat[i].bytes = 0; }
     return TSTAR_OK;
 }
 int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops) {
@@ -66,6 +72,20 @@ int tstar_prof_read(int category, long long* launches, double* total_ms, double*
     std::lock_guard<std::mutex> lk(g_mu);
     drain(g_cat[category]);
     *launches = g_cat[category].launches; *total_ms = g_cat[category].ms; *total_flops = g_cat[category].work;
+    return TSTAR_OK;
+}
+int tstar_prof_read_bytes(int category, double* total_bytes) {
+    TSTAR_REQUIRE(category >= 0 && category < PROF_NCAT && total_bytes, "tstar_prof_read_bytes: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain(g_cat[category]);
+    *total_bytes = g_cat[category].bytes;
+    return TSTAR_OK;
+}
+int tstar_prof_mark(int which, void* stream) {
+    TSTAR_REQUIRE(which == 0 || which == 1, "tstar_prof_mark: which must be 0 (begin) or 1 (end)");
+    if (which == 0) hipLaunchKernelGGL(prof_mark_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    else hipLaunchKernelGGL(prof_mark_end_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
 }
 }

@@ -639,6 +639,16 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
     }
 }
 
+// algorithmic HBM bytes of one conv launch: the input channels it reads (every input pixel once), the output channels it
+// writes, the weights and bias, the residual / attention-gate tensor when fused
+static double conv_algorithmic_bytes(const ConvArgs& a) {
+    const double B = (double)a.M / ((double)a.Ho * a.Wo);
+    double b = 4.0 * B * a.H * a.W * a.cin + 4.0 * a.M * a.cout + 4.0 * a.cout * a.ks * a.ks * a.cin + 4.0 * a.cout;
+    if (a.mode == MODE_RESIDUAL) b += 4.0 * a.M * a.cout;
+    else if (a.mode == MODE_ATTN_MUL) b += 4.0 * a.M * a.heads;
+    return b;
+}
+
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     TSTAR_REQUIRE(a.cout % 4 == 0 && a.dst_ld % 4 == 0 && a.dst_off % 4 == 0, "yolo conv: output channels must be 16-byte aligned");
     const bool tiled = a.cin % CBK == 0 && a.src_ld % 4 == 0 && a.src_off % 4 == 0 && (a.ks == 1 || a.ks == 3);
@@ -661,7 +671,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         const int B = a.M / (a.H * a.W);
         const int mt = B * (a.H / HTH) * (a.W / HTW), nt = cdiv(a.cout, SWN);
         const bool prof = prof_enabled();
-        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
+        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin, conv_algorithmic_bytes(a));
         hipLaunchKernelGGL(conv_halo_kernel, dim3(mt * nt), dim3(256), 0, s, a, mt, nt);
         if (prof) prof_stop(PROF_CONV, s);
     } else if (sw_ok && (sw_env < 0 ? sw_blocks >= sw_min : sw_env > 0)) {
@@ -669,7 +679,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         const int mt = cdiv(a.M, 64 * sw_p), nt = cdiv(a.cout, SWN);
         const dim3 grid(mt * nt);
         const bool prof = prof_enabled();
-        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
+        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin, conv_algorithmic_bytes(a));
         if (sw_p == 8) {
             if (a.ks == 1) hipLaunchKernelGGL((conv_sw_kernel<1, 8>), grid, dim3(256), 0, s, a, mt, nt);
             else hipLaunchKernelGGL((conv_sw_kernel<3, 8>), grid, dim3(256), 0, s, a, mt, nt);
@@ -689,7 +699,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         const int mt = cdiv(a.M, small ? 64 : 128), nt = cdiv(a.cout, wide ? 128 : 64);
         const dim3 grid(mt * nt);
         const bool prof = prof_enabled();
-        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin);
+        if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin, conv_algorithmic_bytes(a));
         if (a.ks == 1) {
             if (wide) hipLaunchKernelGGL((conv_valu_kernel<1, 8, 8>), grid, dim3(256), 0, s, a, mt, nt);
             else if (small) hipLaunchKernelGGL((conv_valu_kernel<1, 4, 4>), grid, dim3(256), 0, s, a, mt, nt);

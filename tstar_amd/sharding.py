@@ -16,6 +16,7 @@ import sys
 from typing import Callable, List, Sequence
 
 _COMM = None            # this process' tstar_comm handle (RCCL communicator created through the C ABI), or False = unavailable
+LAST_GATHER_PATH = None  # which way the last gather_keyframes() went (bench.py reports it as config.collective_path)
 
 
 def _tstar_comm(world: int, rank: int):
@@ -88,8 +89,10 @@ def gather_keyframes(local_rows: Sequence[Sequence[int]], world: int, pad_to: in
     """All-gather int32 [rows_per_rank, K] (padded with -1) -> list of rows in rank-major order.
 
     With world == 1 (or no initialised process group) this is the identity."""
+    global LAST_GATHER_PATH
     rows = [list(map(int, r)) for r in local_rows]
     if world <= 1:
+        LAST_GATHER_PATH = "identity (world 1: nothing to gather)"
         return rows
     import torch
     import torch.distributed as dist
@@ -114,9 +117,13 @@ def gather_keyframes(local_rows: Sequence[Sequence[int]], world: int, pad_to: in
         _lib.check(_lib.load().tstar_allgather_i32(comm, buf.data_ptr(), flat.data_ptr(), nrow * k, _lib.stream_ptr()),
                    "tstar_allgather_i32")
         out = list(flat.cpu())                   # synchronises the stream
+        LAST_GATHER_PATH = (f"tstar_allgather_i32: ncclAllGather on the library's own RCCL communicator "
+                            f"({world} ranks, {nrow * k} int32 per rank, the caller's stream)")
     else:
         out = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(out, buf)
+        LAST_GATHER_PATH = (f"torch.distributed.all_gather over {dist.get_backend()} ({world} ranks)"
+                            + ("; the library's RCCL communicator was unavailable" if on_gpu and nrow * k > 0 else ""))
     res: List[List[int]] = []
     for t in out:
         for row in t.cpu().numpy():
@@ -137,10 +144,24 @@ def interleave_by_item(gathered: List[List[int]], n_items: int, world: int) -> L
     return out
 
 
-def run_sharded(n_items: int, search_item: Callable[[int], Sequence[int]], world: int, rank: int) -> List[List[int]]:
-    """Run ``search_item(item_id) -> keyframe indices`` for this rank's items, gather all results,
-    and return them ordered by item id (identical on every rank)."""
-    mine = [list(search_item(i)) for i in shard_items(n_items, world, rank)]
+def run_sharded(n_items: int, search_item: Callable[[int], Sequence[int]], world: int, rank: int, *,
+                search_group: Callable[[List[int]], Sequence[Sequence[int]]] | None = None, group_size: int = 1) -> List[List[int]]:
+    """Run this rank's items and gather all results, ordered by item id (identical on every rank).
+
+    ``search_item(item_id) -> keyframe indices`` runs one item; with ``search_group`` (``[item ids] -> [keyframe indices
+    per item]``, e.g. a ``tstar_amd.lockstep.search_lockstep`` group) this rank's items are handed over ``group_size`` at a
+    time instead -- results must not depend on the grouping (per-item sampler seeds)."""
+    ids = shard_items(n_items, world, rank)
+    if search_group is not None and group_size > 1:
+        mine = []
+        for g0 in range(0, len(ids), group_size):
+            grp = ids[g0:g0 + group_size]
+            rows = [list(r) for r in search_group(grp)]
+            if len(rows) != len(grp):
+                raise ValueError("run_sharded: search_group must return one row per item")
+            mine.extend(rows)
+    else:
+        mine = [list(search_item(i)) for i in ids]
     gathered = gather_keyframes(mine, world, pad_to=(n_items + world - 1) // world)
     if world <= 1:
         return gathered

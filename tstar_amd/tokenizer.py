@@ -19,15 +19,15 @@ import numpy as np
 
 BOS, EOS, PAD, TEXT_LEN = 49406, 49407, 0, 16
 
-_HF_TOK = None
-_HF_TRIED = False
+_HF_TOK = {}            # model_name_or_path -> CLIPTokenizer or None (tried, not available)
 
 
 def _hf_tokenizer(model_name_or_path: str):
-    global _HF_TOK, _HF_TRIED
-    if _HF_TRIED:
-        return _HF_TOK
-    _HF_TRIED = True
+    """The real CLIP BPE tokenizer of a LOCAL checkpoint directory / HF cache entry (vocab.json + merges.txt), or None."""
+    key = str(model_name_or_path)
+    if key in _HF_TOK:
+        return _HF_TOK[key]
+    tok = None
     try:
         import os
         os.environ.setdefault("HF_HUB_OFFLINE", "1")
@@ -36,10 +36,12 @@ def _hf_tokenizer(model_name_or_path: str):
         # transformers can hand back an EMPTY tokenizer when no vocab is on disk: accept it only if
         # it really is the CLIP BPE vocabulary (BOS 49406 / EOS 49407 around a known word)
         probe = tok(["cat"], padding="max_length", max_length=TEXT_LEN, truncation=True)["input_ids"][0]
-        _HF_TOK = tok if (probe[0] == BOS and probe[2] == EOS and len(tok) >= 49408) else None
+        if not (probe[0] == BOS and probe[2] == EOS and len(tok) >= 49408):
+            tok = None
     except Exception:
-        _HF_TOK = None
-    return _HF_TOK
+        tok = None
+    _HF_TOK[key] = tok
+    return tok
 
 
 def standin_word_id(word: str) -> int:
