@@ -20,6 +20,10 @@ def make_checkpoint_dir(dirpath: str, seed: int = 0):
         for lin in (m.class_head.logit_scale, m.class_head.logit_shift):
             lin.weight.mul_(0.01)
             lin.bias.mul_(0.01)
+        # same for the box head: its three unit-variance Linear layers put the box logits in the tens of thousands (every
+        # coordinate a saturated 0 / 1, and the few in transition ill-conditioned); 1/sqrt(fan_in) brings them to O(1)
+        for lin in (m.box_head.dense0, m.box_head.dense1, m.box_head.dense2):
+            lin.weight.mul_(lin.weight.shape[1] ** -0.5)
     os.makedirs(dirpath, exist_ok=True)
     m.save_pretrained(dirpath, safe_serialization=True)
     write_clip_vocab(dirpath)

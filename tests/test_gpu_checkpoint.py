@@ -56,6 +56,8 @@ def test_checkpoint_directory_through_the_gpu_path(ckpt):
         assert len(det) == len(ref["scores"]) == 576                         # threshold 0.005: every patch kept, patch order
         assert np.abs(det.confidence - ref["scores"]).max() < 1e-3
         assert np.abs(det.xyxy - ref["xyxy"]).max() < 1e-2                   # pixels of the passed image
+        wh = ref["xyxy"][:, 2:] - ref["xyxy"][:, :2]
+        assert wh.min() > 1.0 and wh.max() < max(H_, W_)                     # real boxes, not saturated sigmoids
         top2 = np.sort(ref["logits"], axis=1)[:, -2:]
         clear = (top2[:, 1] - top2[:, 0]) > 1e-3                             # arg-max is only defined up to the logit tolerance
         assert clear.mean() > 0.9 and np.array_equal(det.class_id[clear], ref["labels"][clear])
