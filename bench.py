@@ -55,10 +55,11 @@ def parse():
     ap.add_argument("--max-batch", type=int, default=256, help="detector images per forward chunk")
     ap.add_argument("--nframes", type=int, default=N_FRAMES)
     ap.add_argument("--search-nframes", type=int, default=8)
-    ap.add_argument("--weights", choices=["f32", "bf16", "f32_split"], default="f32",
-                    help="bf16 = BASELINE config 5 (bf16-rounded weights, exact-split bf16 MFMA GEMMs); with "
-                         "--nframes 14400 --grid 15 --search-nframes 32 this is configs[4].  f32_split = fp32 checkpoint "
-                         "with every operand carried as two bf16 terms on the bf16 matrix pipe (opt-in)")
+    ap.add_argument("--weights", choices=["f32", "bf16", "bf16_exact", "f32_split"], default="f32",
+                    help="bf16 = BASELINE config 5 (bf16-rounded weights on the bf16 matrix pipe, f32 activations as two bf16 terms: "
+                         "2 MFMA products per algorithmic product); with --nframes 14400 --grid 15 --search-nframes 32 this is "
+                         "configs[4].  bf16_exact = the same weights with the activations split exactly into three terms (3 products). "
+                         "f32_split = fp32 checkpoint with every operand carried as two bf16 terms (opt-in, no longer maintained)")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="independent searches in flight per GPU (host threads, one HIP stream + one scorer "
                          "workspace each); 2 fills kernel tails and gives ~+5 %% throughput, but overlapping "
@@ -535,8 +536,10 @@ def main():
                     break
                 except Exception:
                     pass
-    elif args.weights in ("bf16", "f32_split"):
-        gemm_kernel, peak, exec_mult = f"gemm_f32_kernel<WMODE={1 if args.weights == 'bf16' else 2}> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
+    elif args.weights == "bf16":
+        gemm_kernel, peak, exec_mult = "gemm_bf16w2_wide_kernel / gemm_f32_kernel<WMODE=3> (2 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 2.0
+    elif args.weights in ("bf16_exact", "f32_split"):
+        gemm_kernel, peak, exec_mult = f"gemm_f32_kernel<WMODE={1 if args.weights == 'bf16_exact' else 2}> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
     else:
         gemm_kernel, peak, exec_mult = "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1.0
     # post-run parity check of the keyframes this run produced (rank 0, step 0): solo re-run + oracle replay, untimed
@@ -565,7 +568,8 @@ def main():
             "metric": "candidate frames scored/sec (whole node) + sec/video to 8 keyframes, 1h@1fps",
             "value": frames_all / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16": "f32 activations x bf16 weights (exact 3-term split on the bf16 MFMA pipe)",
+            "dtype": {"f32": "f32", "bf16": "f32 activations (two round-to-nearest bf16 terms) x bf16 weights, exact products, f32 accumulate",
+                      "bf16_exact": "f32 activations x bf16 weights (exact 3-term split on the bf16 MFMA pipe)",
                       "f32_split": "f32 operands as 2 bf16 terms each (16 significand bits), 3 bf16 MFMA products, f32 accumulate"}[args.weights],
             "data": "synthetic",
             "config": {

@@ -62,17 +62,24 @@ typedef struct tstar_owl tstar_owl;
  *     arithmetic and the mode every headline number is quoted in.
  *   TSTAR_WEIGHTS_BF16 (1) (BASELINE config 5, "bf16 ViT weights"): every GEMM weight matrix is also kept
  *     as bfloat16 (round to nearest even; exact if the blob already holds bf16 values) and the GEMMs run
- *     on the bf16 matrix pipe with the float32 activations split exactly into three bf16 terms -- an
- *     f32-accumulated product of f32 activations and bf16 weights.  The vision tower's attention runs on the
- *     bf16 pipe as well in modes 1 and 2 (f32-split operands: two bf16 terms each, 3 products, f32 accumulation).
+ *     on the bf16 matrix pipe.  A bf16 weight is exact in ONE term; the float32 activations are carried as TWO
+ *     round-to-nearest bf16 terms a_hi + a_lo (16 significand bits, |a - a_hi - a_lo| <= 2^-17 |a|):
+ *     C += a_lo*w + a_hi*w, exact products, f32 accumulation -- 2 MFMA products per algorithmic product.
+ *     Detector scores stay within 1e-3 of a float32 run on the same rounded weights (tests state the measured
+ *     bound, ~1e-5).  The vision tower's attention runs on the bf16 pipe as well in modes 1-3 (f32-split
+ *     operands: two bf16 terms each, 3 products, f32 accumulation).
  *   TSTAR_WEIGHTS_F32_SPLIT (2): float32 checkpoints on the bf16 matrix pipe: each weight is kept as two
  *     bfloat16 terms hi + lo and each activation is split into two terms on the fly (round to nearest,
  *     16 significand bits per operand); C += a_lo*w_hi + a_hi*w_lo + a_hi*w_hi with exact products and f32
  *     accumulation (the 2^-18 a_lo*w_lo term is dropped).  Detector scores stay within 1e-3 of the
- *     float32 path (tests state the measured bound); opt-in, never the default. */
+ *     float32 path (tests state the measured bound); opt-in, never the default.
+ *   TSTAR_WEIGHTS_BF16_EXACT (3): bf16 weights with the activations split EXACTLY into three bf16 terms
+ *     (8 + 8 + 8 significand bits, truncation split; 3 MFMA products): the f32-accumulated product of the f32
+ *     activations with the bf16 weights, f32-roundoff class (round 1-2's bf16 mode, kept selectable). */
 #define TSTAR_WEIGHTS_F32 0
 #define TSTAR_WEIGHTS_BF16 1
 #define TSTAR_WEIGHTS_F32_SPLIT 2
+#define TSTAR_WEIGHTS_BF16_EXACT 3
 int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision,
                      const float* h_text_blob, size_t n_text, const float* h_norm_lut, int max_batch,
                      int weights_mode);
@@ -280,6 +287,13 @@ int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const flo
 /* bf16-weight GEMM (diagnostic): W is rounded to bfloat16 on the device, A is split exactly; synchronises */
 int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                      int M, int N, int K, int act, int tile_cfg, void* stream);
+/* bf16-weight GEMM with two-term activations (diagnostic; tile_cfg 4 forces the 128x256 tile, 5 forbids it) */
+int tstar_gemm_bf16w2(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
+                      int M, int N, int K, int act, int tile_cfg, void* stream);
+/* bf16-weight GEMM on weights that are ALREADY bfloat16 on the device (d_Wb: [N, K] bf16); a_terms 2 or 3; enqueues only
+ * (microbenchmarks) */
+int tstar_gemm_bf16w_pre(const float* d_A, const void* d_Wb, float* d_C, const float* d_bias, const float* d_residual,
+                         int M, int N, int K, int act, int a_terms, int tile_cfg, void* stream);
 /* f32-split GEMM (diagnostic): W is split into two bfloat16 terms on the device, A into two on the fly; synchronises */
 int tstar_gemm_f32_split(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                          int M, int N, int K, int act, int tile_cfg, void* stream);

@@ -525,17 +525,20 @@ def test_g9_end_to_end_vs_reference(golden_dir):
           f"{[float(t) for t in ts]} vs reference {g['time_stamps'].tolist()}")
 
 
-def test_config5_four_hour_video_bf16_weights():
+@pytest.mark.parametrize("mode,max_batch,tol", [("bf16", 64, 1e-4), ("bf16_exact", 32, 2e-5)])
+def test_config5_four_hour_video_bf16_weights(mode, max_batch, tol):
     """BASELINE config 5: 14400-frame video, search_nframes=32, grid 15x15 (225 frames/iter -> exactly 5
     iterations under the 1000-frame cap), bf16-rounded weights.  Checked teacher-forced against the CPU
-    oracle running on the SAME rounded weights."""
+    oracle running on the SAME rounded weights.  "bf16" = two-term activations (2 MFMA products per algorithmic
+    product, the 128x256 tile on the 64-image verification chunks), "bf16_exact" = the exact three-term split; the
+    contract is 1e-3 on the scores, the asserted bounds are what the modes actually deliver with a margin."""
     from oracle import owl_ref, resize_ref as R, searcher_ref as S
     from tstar_amd import weights as W
     from tstar_amd.interface_heuristic import OWLInterface
     from tstar_amd.interface_searcher import TStarSearcher
     from tstar_amd.video import synthetic_frames_numpy, synthetic_video
     N, g, K = 14400, 15, 32
-    h = OWLInterface(synthetic_seed=0, max_batch=32, weights_dtype="bf16")
+    h = OWLInterface(synthetic_seed=0, max_batch=max_batch, weights_dtype=mode)
     rec = _Recorder(h)
     store = synthetic_video(N, seed=11)
     s = TStarSearcher(store, h, ["couch"], ["tv", "chair"], search_nframes=K, image_grid_shape=(g, g),
@@ -573,7 +576,19 @@ def test_config5_four_hour_video_bf16_weights():
     assert np.array_equal(rec.calls[0]["images"][0], grid_ref)
     o = owl_ref.detect(R.owl_preprocess(grid_ref)[None], h.scorer.get_query_embeds(), wv, grid_ref.shape[0],
                        grid_ref.shape[1], query_mask=np.ones(len(names), bool))
-    assert np.abs(o["dense"][0][0] - rec.calls[0]["scores"][0]).max() < 1e-3
+    err = float(np.abs(o["dense"][0][0] - rec.calls[0]["scores"][0]).max())
+    print(f"config 5, weights {mode}: max |score - CPU f32 on the same rounded weights| = {err:.2e} (contract 1e-3)")
+    assert err < tol, err
+    # a 64-image verification-size batch (the wide-tile launches in "bf16" mode) against per-image CPU scores
+    vf = synthetic_frames_numpy(secs0[:3], N, seed=11)
+    vimgs = np.stack([R.cv_bilinear_resize(f, 600, 285) for f in vf])
+    big = torch.from_numpy(np.concatenate([vimgs] * 22)[:64]).cuda()
+    rb = h.score_batch(big, 1, 1)
+    for k in range(3):
+        ok_ = owl_ref.detect(R.owl_preprocess(vimgs[k])[None], h.scorer.get_query_embeds(), wv, 285, 600, query_mask=np.ones(len(names), bool))
+        e2 = float(np.abs(ok_["dense"][0][0] - rb.scores[k].cpu().numpy()).max())
+        assert e2 < tol, (k, e2)
+        assert torch.equal(rb.scores[k], rb.scores[k + 3 * 20])          # same image elsewhere in the batch: same bits
     # rounding really happened: a weight matrix holds only bf16-representable values
     m = sd["owlvit.vision_model.encoder.layers.0.mlp.fc1.weight"]
     assert np.all((m.view(np.uint32) & 0xFFFF) == 0)

@@ -100,8 +100,8 @@ struct tstar_owl {
     int *d_ids = nullptr, *d_eos = nullptr;
     uint8_t* d_kmask = nullptr;
     std::map<int, ResampleTable> tabs;   // in_size -> table to 768
-    // weights_mode 1 (BASELINE config 5, bf16 weights): bfloat16 copy of every GEMM weight matrix;
-    // weights_mode 2 (f32 split): two bfloat16 terms hi + lo per matrix (16 significand bits)
+    // weights_mode 1 / 3 (BASELINE config 5, bf16 weights; two-term / exact three-term activations): bfloat16 copy of every
+    // GEMM weight matrix; weights_mode 2 (f32 split): two bfloat16 terms hi + lo per matrix (16 significand bits)
     int weights_mode = TSTAR_WEIGHTS_F32;
     std::unordered_map<const float*, __bf16*> wb, wb_lo;
     const __bf16* bf16_of(const float* w) const {
@@ -172,6 +172,7 @@ static GemmArgs mk_gemm(const tstar_owl* h, const float* A, const float* W, floa
     GemmArgs g{};
     g.A = A; g.W = W; g.Wb = h ? h->bf16_of(W) : nullptr; g.Wb2 = h ? h->bf16_lo_of(W) : nullptr; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0; g.tile_cfg = -1; g.m_split = 0;
+    g.a_terms = h && h->weights_mode == TSTAR_WEIGHTS_BF16 ? 2 : 0;      // bf16 weights: two-term activations unless the exact mode is asked for
     return g;
 }
 
@@ -256,8 +257,8 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
     TSTAR_REQUIRE(!h_vision_blob || h_norm_lut, "tstar_owl_create: the vision tower needs the normalisation LUT");
     TSTAR_REQUIRE(h_vision_blob || weights_mode == TSTAR_WEIGHTS_F32, "tstar_owl_create: a text-only handle runs in float32");
     TSTAR_REQUIRE(max_batch >= 1 && max_batch <= 1024, "tstar_owl_create: max_batch must be in 1..1024");
-    TSTAR_REQUIRE(weights_mode >= TSTAR_WEIGHTS_F32 && weights_mode <= TSTAR_WEIGHTS_F32_SPLIT,
-                  "tstar_owl_create: weights_mode must be 0 (f32), 1 (bf16) or 2 (f32 split)");
+    TSTAR_REQUIRE(weights_mode >= TSTAR_WEIGHTS_F32 && weights_mode <= TSTAR_WEIGHTS_BF16_EXACT,
+                  "tstar_owl_create: weights_mode must be 0 (f32), 1 (bf16), 2 (f32 split) or 3 (bf16, exact three-term activations)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         set_error("tstar_owl_create: no HIP device visible (this library has no CPU path)");
@@ -521,7 +522,7 @@ int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const flo
     return gemm_f32(g, (hipStream_t)stream);
 }
 
-static int gemm_converted(const char* fn, bool split, const float* d_A, const float* d_W, float* d_C, const float* d_bias,
+static int gemm_converted(const char* fn, bool split, int a_terms, const float* d_A, const float* d_W, float* d_C, const float* d_bias,
                           const float* d_residual, int M, int N, int K, int act, int tile_cfg, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     __bf16 *wb = nullptr, *lo = nullptr;
@@ -536,6 +537,7 @@ static int gemm_converted(const char* fn, bool split, const float* d_A, const fl
         GemmArgs g = mk_gemm(nullptr, d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
         g.Wb = wb;
         g.Wb2 = lo;
+        g.a_terms = a_terms;
         g.tile_cfg = tile_cfg;
         rc = gemm_f32(g, s);
     }
@@ -549,13 +551,30 @@ static int gemm_converted(const char* fn, bool split, const float* d_A, const fl
 int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
                      int N, int K, int act, int tile_cfg, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_bf16w: null argument");
-    return gemm_converted("tstar_gemm_bf16w", false, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
+    return gemm_converted("tstar_gemm_bf16w", false, 0, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
+}
+
+int tstar_gemm_bf16w_pre(const float* d_A, const void* d_Wb, float* d_C, const float* d_bias, const float* d_residual, int M, int N,
+                         int K, int act, int a_terms, int tile_cfg, void* stream) {
+    TSTAR_REQUIRE(d_A && d_Wb && d_C, "tstar_gemm_bf16w_pre: null argument");
+    TSTAR_REQUIRE(a_terms == 2 || a_terms == 3, "tstar_gemm_bf16w_pre: a_terms must be 2 or 3");
+    GemmArgs g = mk_gemm(nullptr, d_A, reinterpret_cast<const float*>(d_Wb), d_C, d_bias, d_residual, M, N, K, K, N, act);
+    g.Wb = static_cast<const __bf16*>(d_Wb);
+    g.a_terms = a_terms;
+    g.tile_cfg = tile_cfg;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+
+int tstar_gemm_bf16w2(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
+                      int N, int K, int act, int tile_cfg, void* stream) {
+    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_bf16w2: null argument");
+    return gemm_converted("tstar_gemm_bf16w2", false, 2, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
 }
 
 int tstar_gemm_f32_split(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
                          int N, int K, int act, int tile_cfg, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32_split: null argument");
-    return gemm_converted("tstar_gemm_f32_split", true, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
+    return gemm_converted("tstar_gemm_f32_split", true, 0, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
 }
 
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream) {

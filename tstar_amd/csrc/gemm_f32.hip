@@ -54,6 +54,7 @@ struct Cfg { static constexpr int TM = TM_, TN = TN_, MINW = MINW_, BM = 2 * TM_
 using Cfg128 = Cfg<2, 2, 2>;
 using Cfg64N = Cfg<1, 2, 2>;
 using Cfg64 = Cfg<1, 1, 4>;
+using Cfg128W = Cfg<2, 4, 2>;      // 128x256 block (each wave 64x128): the two-term bf16-weight tile, where LDS traffic per MFMA decides
 
 // Epilogue shared by the f32 and the bf16-pipe tiles.  C/D layout of the 32x32 MFMA:
 // col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -108,9 +109,65 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
     }
 }
 
+// The 128x256 tile carries 128 accumulator registers into the epilogue.  Same scheme as above, but row-major over the
+// sub-tiles (the 16 row offsets of a 32-row band are formed once, as 32-bit element offsets, and serve its four column
+// tiles) with a scheduling barrier per sub-tile: in the column-major order the compiler kept the 64-bit offsets of all 32
+// rows live across the column tiles and spilled ~130 registers to scratch.
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH, bool GUARD>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, f32x16 (&acc)[CF::TM][CF::TN], const int m0, const int n0,
+                                                   const int wm, const int wn, const int l31, const int h) {
+    constexpr int TM = CF::TM, TN = CF::TN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * h;
+        unsigned roff[16], poff[PATCH ? 16 : 1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (GUARD) row = row < g.M ? row : g.M - 1;
+            unsigned orow = (unsigned)row;
+            if (PATCH) {
+                const int b = row / g.patch_np, p = row - b * g.patch_np;
+                orow = (unsigned)(b * (g.patch_np + 1) + 1 + p);
+                poff[r] = (unsigned)(1 + p) * (unsigned)g.N;
+            }
+            roff[r] = orow * (unsigned)g.ldc;                 // element offsets fit 32 bits (checked by the launcher)
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + l31;
+            const float bv = HAS_BIAS ? g.bias[col] : 0.f;
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = 0.f;
+                if (PATCH) x = g.pos[(size_t)poff[r] + col];
+                if (HAS_RES) x += g.res[(size_t)roff[r] + col];
+                e[r] = x;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = epi_act(acc[i][j][r] + bv, ACT);
+                if (PATCH || HAS_RES) v += e[r];
+                e[r] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!GUARD || rbase + (r & 3) + 8 * (r >> 2) < g.M) g.C[(size_t)roff[r] + col] = e[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[CF::TM][CF::TN], const int m0, const int n0,
                                               const int wm, const int wn, const int l31, const int h) {
+    if constexpr (CF::TN >= 4) {
+        if (m0 + CF::BM <= g.M) gemm_epilogue_wide<CF, ACT, HAS_BIAS, HAS_RES, PATCH, false>(g, acc, m0, n0, wm, wn, l31, h);
+        else gemm_epilogue_wide<CF, ACT, HAS_BIAS, HAS_RES, PATCH, true>(g, acc, m0, n0, wm, wn, l31, h);
+        return;
+    }
     if (m0 + CF::BM <= g.M) gemm_epilogue_impl<CF, ACT, HAS_BIAS, HAS_RES, PATCH, false>(g, acc, m0, n0, wm, wn, l31, h);
     else gemm_epilogue_impl<CF, ACT, HAS_BIAS, HAS_RES, PATCH, true>(g, acc, m0, n0, wm, wn, l31, h);
 }
@@ -176,10 +233,22 @@ __device__ __forceinline__ void split4_bf16x2(const f32x4 v, u32x2 (&out)[2]) {
 //          nearest), activations split into 2 terms, C += a_lo*w_hi + a_hi*w_lo + a_hi*w_hi (the
 //          a_lo*w_lo term, 2^-18 relative, is dropped): 3 MFMAs per K = 16 like mode 1, operands
 //          carry 16 significand bits, products are exact, accumulation is f32.
+// WMODE 3: bf16 weights (exact in ONE term), activations as TWO round-to-nearest bf16 terms a_hi + a_lo
+//          (16 significand bits, |a - a_hi - a_lo| <= 2^-17 |a|): C += a_lo*w + a_hi*w, 2 MFMAs per K = 16
+//          instead of 3.  Products are exact, accumulation is f32; the dropped third term is 2^-17 relative
+//          per product with random sign -- three orders of magnitude inside the 1e-3 score contract (tests
+//          state the measured bound).  The default of BASELINE config 5; mode 1 stays selectable.
+//          With two thirds of the MFMAs the 128x128 tile would be bound by LDS traffic (A is written as two
+//          planes and read back once per N tile: 499 LDS cycles against 512 matrix-pipe cycles per K tile),
+//          so whole waves of the launch use a 128x256 tile (Cfg128W, each wave 64x128: 8 fragment reads per
+//          16 MFMAs instead of 6 per 8; 666 LDS cycles against 1024), register prefetch one K tile deep
+//          (a K tile is 1024 matrix-pipe cycles per wave, two waves per SIMD: longer than an L2 round trip).
 template <class CF, int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0, const int n0, float* smem_f) {
     constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM, BN = CF::BN;
-    constexpr int NAT = WMODE == 2 ? 2 : 3, NWT = WMODE == 2 ? 2 : 1;     // operand terms
+    constexpr int NAT = WMODE == 1 ? 3 : 2, NWT = WMODE == 2 ? 2 : 1;     // operand terms
+    constexpr int NPROD = WMODE == 3 ? 2 : 3;                             // MFMA products per algorithmic product
+    constexpr int DEPTH = TN >= 4 ? 1 : 2;                                // register prefetch depth in K tiles
     constexpr int A_T = BM * 64, W_T = BN * 64, BUF = NAT * A_T + NWT * W_T;       // bytes
     char* smem = reinterpret_cast<char*>(smem_f);
     const int t = threadIdx.x;
@@ -211,8 +280,8 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
     // Register prefetch is TWO K tiles deep (sets 0/1): with the bf16 pipe a K tile is only ~770 matrix-pipe
     // cycles per wave, less than one L2 round trip, so a one-deep prefetch (as in the f32 tile, whose K tile
     // is 4096 cycles) would expose the load latency at every tile.
-    f32x4 ra[2][NA];
-    u32x4 rb[2][NWT][NB];
+    f32x4 ra[DEPTH][NA];
+    u32x4 rb[DEPTH][NWT][NB];
     auto gload = [&](auto SET, int kt) __attribute__((always_inline)) {
         constexpr int st = decltype(SET)::value;
 #pragma unroll
@@ -229,8 +298,8 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             u32x2 sp[NAT];
-            if constexpr (WMODE == 2) split4_bf16x2(ra[st][i], sp);
-            else split4_bf16x3(ra[st][i], sp);
+            if constexpr (WMODE == 1) split4_bf16x3(ra[st][i], sp);
+            else split4_bf16x2(ra[st][i], sp);
             const int off = bfw_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
 #pragma unroll
             for (int k = 0; k < NAT; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
@@ -257,9 +326,9 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     fw[w][j] = *reinterpret_cast<const bf16x8*>(base + NAT * A_T + w * W_T + bfw_off(wn * TN * 32 + j * 32 + l31, 2 * s + h));
-            // smallest term first: mode 1 a2*w, a1*w, a0*w; mode 2 a_lo*w_hi, a_hi*w_lo, a_hi*w_hi
+            // smallest term first: mode 1 a2*w, a1*w, a0*w; mode 2 a_lo*w_hi, a_hi*w_lo, a_hi*w_hi; mode 3 a_lo*w, a_hi*w
 #pragma unroll
-            for (int p = 2; p >= 0; --p) {
+            for (int p = NPROD - 1; p >= 0; --p) {
                 const int ka = WMODE == 2 ? (p == 2 ? 1 : 0) : p;
                 const int kw = WMODE == 2 ? (p == 1 ? 1 : 0) : 0;
 #pragma unroll
@@ -272,10 +341,24 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
         __builtin_amdgcn_s_setprio(0);
     };
     using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
+    using S1 = std::integral_constant<int, DEPTH - 1>;      // (DEPTH == 1 never reaches the two-deep loop below)
     const int nk = g.K / BK;
+    if constexpr (DEPTH == 1) {
+        gload(S0{}, 0);
+        lstore(S0{}, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) gload(S0{}, kt + 1);
+            compute(kt & 1);
+            if (more) lstore(S0{}, (kt + 1) & 1);
+            __syncthreads();
+        }
+        gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
+        return;
+    }
     gload(S0{}, 0);
-    if (nk > 1) gload(S1{}, 1);
+    if (nk > 1) gload(std::integral_constant<int, DEPTH - 1>{}, 1);
     lstore(S0{}, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
@@ -415,10 +498,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_hybrid_kernel(GemmArgs g) {
     }
 }
 
+// Wide hybrid launch of the two-term bf16-weight mode: rows [0, m_split) in 128x256 tiles (whole waves of the 512
+// resident slots), the remaining rows in 64x128 tiles that arrive last and fill the tail.
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__global__ __launch_bounds__(256, 2) void gemm_bf16w2_wide_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ntw = g.N / 256;
+    const int n_big = (g.m_split / 128) * ntw;
+    if ((int)blockIdx.x < n_big) {
+        const int tile = xcd_remap(blockIdx.x, n_big);
+        gemm_tile_bf16w<Cfg128W, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / ntw) * 128, (tile % ntw) * 256, smem);
+    } else {
+        const int nt = g.N / 128;
+        const int n_small = gridDim.x - n_big;
+        const int tile = xcd_remap(blockIdx.x - n_big, n_small);
+        gemm_tile_bf16w<Cfg64N, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+    }
+}
+
 // dynamic LDS of one block: double-buffered operand tiles
 template <int WMODE>
 constexpr int lds_bytes(int bm, int bn) {
-    return WMODE == 2 ? 2 * (2 * bm + 2 * bn) * 64 : WMODE == 1 ? 2 * (3 * bm + bn) * 64 : 2 * (bm + bn) * LDS_LD * 4;
+    return WMODE == 3 ? 2 * (2 * bm + bn) * 64 : WMODE == 2 ? 2 * (2 * bm + 2 * bn) * 64 : WMODE == 1 ? 2 * (3 * bm + bn) * 64 : 2 * (bm + bn) * LDS_LD * 4;
 }
 
 // algorithmic HBM bytes of one launch: A and W read once, C written once, residual read once, bias / position rows
@@ -449,6 +550,20 @@ static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     const int nt = g.N / 128;
     const int nwg = (g.m_split / 128) * nt + cdiv(g.M - g.m_split, 64) * nt;
+    const bool prof = prof_enabled();
+    if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K, gemm_algorithmic_bytes(g));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, g);
+    if (prof) prof_stop(PROF_GEMM, stream);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+static int launch_wide(const GemmArgs& g, hipStream_t stream) {
+    constexpr int lds = lds_bytes<3>(128, 256);
+    auto kern = gemm_bf16w2_wide_kernel<ACT, HAS_BIAS, HAS_RES, PATCH>;
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+    const int nwg = (g.m_split / 128) * (g.N / 256) + cdiv(g.M - g.m_split, 64) * (g.N / 128);
     const bool prof = prof_enabled();
     if (prof) prof_start(PROF_GEMM, stream, 2.0 * g.M * g.N * g.K, gemm_algorithmic_bytes(g));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, stream, g);
@@ -500,8 +615,28 @@ static int pick_cfg(int M, int N, int* m_split) {
 template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_mode(const GemmArgs& g, hipStream_t stream) {
     const int forced = g.tile_cfg;                           // -1 = auto
+    if constexpr (WMODE == 3) {
+        // two-term mode: from one wave (512) of 128x256 tiles on, whole waves of them; the remaining full panels are wide
+        // too when they make more than half a wave (a 64x128 tile of this mode is LDS-bound and runs at ~0.7 of the wide
+        // tile's rate: three rounds of them cost more than one round of wide tiles -- tools/bench_gemm_bf16.py: out-proj
+        // at B = 64, 864 wide tiles: 410 all wide vs 384 with a narrow tail), else they and the ragged rows go out as
+        // 64x128 tiles that fill the tail (tile_cfg 4 forces every full 128-row panel wide; 5 forces the wide tile OFF)
+        if (g.N % 256 == 0 && forced != 5 && (forced == -1 || forced == 4)) {
+            const int ntw = g.N / 256, mt = g.M / 128;       // full 128-row panels only
+            const long long bw = (long long)mt * ntw;
+            int big = 0;
+            if (forced == 4) big = mt;
+            else if (bw >= 512) big = (bw % 512) > 256 ? mt : (int)(((bw / 512) * 512) / ntw);
+            const bool fits32 = ((long long)(g.M + g.M / (g.patch_np > 0 ? g.patch_np : g.M) + 1) * g.ldc) < (1ll << 32);   // the wide epilogue's offsets
+            if (big > 0 && fits32) {
+                GemmArgs h = g;
+                h.m_split = big * 128;
+                return launch_wide<ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
+            }
+        }
+    }
     int m_split = 0;
-    int cfg = forced >= 0 ? forced : pick_cfg(g.M, g.N, &m_split);
+    int cfg = (forced >= 0 && forced <= 3) || forced >= 16 ? forced : pick_cfg(g.M, g.N, &m_split);
     if (forced == 3) {                                       // forced hybrid: half of the row tiles big
         m_split = (cdiv(g.M, 128) / 2) * 128;
         if (m_split == 0) cfg = 1;
@@ -523,6 +658,7 @@ static int launch_mode(const GemmArgs& g, hipStream_t stream) {
 template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_one(const GemmArgs& g, hipStream_t stream) {
     if (g.Wb && g.Wb2) return launch_mode<2, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (g.Wb && g.a_terms == 2) return launch_mode<3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
     if (g.Wb) return launch_mode<1, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
     return launch_mode<0, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
 }
@@ -532,7 +668,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t stream) {
     TSTAR_REQUIRE(g.N % 128 == 0, "gemm_f32: N must be a multiple of 128");
     TSTAR_REQUIRE(g.K % BK == 0, "gemm_f32: K must be a multiple of 32");
     TSTAR_REQUIRE(g.lda % 4 == 0 && g.K % 4 == 0, "gemm_f32: rows must be 16-byte aligned");
-    TSTAR_REQUIRE((g.tile_cfg >= -1 && g.tile_cfg <= 3) || g.tile_cfg >= 16, "gemm_f32: tile_cfg must be -1..3 (or 16 + big row tiles)");
+    TSTAR_REQUIRE((g.tile_cfg >= -1 && g.tile_cfg <= 5) || g.tile_cfg >= 16, "gemm_f32: tile_cfg must be -1..5 (or 16 + big row tiles)");
     const bool bias = g.bias != nullptr, res = g.res != nullptr, patch = g.pos != nullptr;
     if (patch) {
         TSTAR_REQUIRE(!bias && !res && g.act == ACT_NONE && g.patch_np > 0, "gemm_f32: patch epilogue takes no bias/res/act");

@@ -67,9 +67,11 @@ class OWLInterface(HeuristicInterface):
         ``model_name_or_path`` if one exists on disk; else, only when ``synthetic_seed`` is not None,
         seeded synthetic weights (no checkpoint can be downloaded: there is no network).
         ``weights_dtype="bf16"`` rounds every weight matrix to bfloat16 (BASELINE config 5) and runs the
-        GEMMs on the bf16 matrix pipe with the float32 activations split exactly into three bf16 terms:
-        products are exact and accumulate in float32, so the result equals a CPU float32 run on the
-        same rounded weights up to summation order.
+        GEMMs on the bf16 matrix pipe with the float32 activations carried as two round-to-nearest bf16
+        terms (16 significand bits): products are exact and accumulate in float32; scores stay within
+        ~1e-5 of a CPU float32 run on the same rounded weights (contract 1e-3).  ``"bf16_exact"`` splits
+        the activations exactly into three terms instead (3 matrix products per algorithmic product):
+        equal to that CPU run up to summation order.
 
         ``allow_standin_tokenizer``: the hash stand-in of tstar_amd.tokenizer is only meaningful with
         synthetic weights; default (None) = allowed exactly when the weights are the seeded synthetic
@@ -99,9 +101,9 @@ class OWLInterface(HeuristicInterface):
         if allow_standin_tokenizer is None:
             allow_standin_tokenizer = self.weights_source.startswith("synthetic(")
         self.allow_standin_tokenizer = bool(allow_standin_tokenizer)
-        if weights_dtype not in ("f32", "bf16", "f32_split"):
-            raise ValueError("weights_dtype must be 'f32', 'bf16' or 'f32_split'")
-        if weights_dtype == "bf16":
+        if weights_dtype not in ("f32", "bf16", "bf16_exact", "f32_split"):
+            raise ValueError("weights_dtype must be 'f32', 'bf16', 'bf16_exact' or 'f32_split'")
+        if weights_dtype in ("bf16", "bf16_exact"):
             state_dict = W.round_weights_to_bf16(state_dict)
         self.weights_dtype = weights_dtype
         self.model_name_or_path = model_name_or_path
