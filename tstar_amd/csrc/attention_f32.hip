@@ -43,6 +43,18 @@
 //    tiles of a head on one L2: 119.8 -- the K/V re-reads already hit; 2-wave workgroups with 64 queries per wave (two Q
 //    fragments share every K / V fragment read: half the LDS fragment traffic per MFMA, 2 + 4 independent MFMA chains, 235
 //    VGPRs = 2 waves / SIMD): 114.7 vs 119.2 -- the LDS fragment reads are not the limiter either.
+//    Round 3, the one bounded experiment the review asked for (commit "attention: VALU straggler query"): the wave whose tile
+//    holds the single straggler query (T - 1 = 576) scores it with VALU ops from the K / V tiles the block stages anyway
+//    (32 FMAs + two 5-step wave reductions + 32 readlane/FMA per key tile; every lane of that wave already holds the query in
+//    fragment layout) instead of a 19th MFMA wave tile: 5.3 % fewer MFMAs.  Same-session A/B, three alternations:
+//    B = 256: 111.1 / 112.9 / 113.8 (round-2 kernel) vs 110.9 / 112.5 / 112.6; B = 64: 95.2 / 96.0 / 96.0 vs 98.0 / 97.8 / 97.9.
+//    No gain at the bench's batch size (gate was 125): removing MFMA work does not shorten anything, because the cost of
+//    T = 4 x 128 + 65 is SLOT occupancy -- the fifth workgroup of every head holds its CU slot (LDS, 4 wave slots) for all
+//    18 key tiles with two of its four waves working: 20 wave slots for 18.03 tiles of queries = the 0.90 already
+//    accounted for.  The 16x16x4 MFMA shape itself has the same rate (2048 flops / 32 cycles) and the same accumulator
+//    footprint per query as 32x32x2, so it buys registers only with fewer queries per wave, i.e. more K / V staging per
+//    MFMA (the 3- / 6-wave result above); what would recover the 10 % is a fifth workgroup that finishes in half the
+//    time (16 queries per wave there): a second loop body in this kernel for +0.9 % of a step -- not built.  Topic closed.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
