@@ -53,6 +53,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=16, help="grid side g (g*g frames per iteration)")
     ap.add_argument("--max-batch", type=int, default=256, help="detector images per forward chunk")
+    ap.add_argument("--yolo-max-batch", type=int, default=76,
+                    help="YOLO-World backend: detector images per forward chunk.  Sized for the chip, not a power of two: the halo conv "
+                         "kernel holds 3 workgroups per CU (768 slots) and a 40x40 / 256-channel layer is 20 B workgroups, an 80x80 / 128 "
+                         "layer 40 B, a 160x160 / 64 layer 80 B -- B = 38 fills exactly 1 / 2 / 4 rounds, 76 twice that (B = 32 leaves a "
+                         "sixth of the slots idle: 84.7 vs 91.8 / 98.3 TFLOP/s per forward, tools/yolo_batch_sweep.py); with 16 searches "
+                         "in lock-step an iteration verifies about 150 frames = two chunks of 76 (+ a small remainder)")
     ap.add_argument("--nframes", type=int, default=N_FRAMES)
     ap.add_argument("--search-nframes", type=int, default=8)
     ap.add_argument("--weights", choices=["f32", "bf16", "bf16_exact", "f32_split"], default="f32",
@@ -67,7 +73,8 @@ def parse():
     ap.add_argument("--lockstep", type=int, default=0,
                     help="independent (video, question) items advanced in lock-step per detector batch "
                          "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time; default 4 "
-                         "with the OWL-ViT backend, 8 with YOLO-World (its small grid forwards gain from B = 8: +8 %%)")
+                         "with the OWL-ViT backend, 16 with YOLO-World (its grid forwards run at B = the group size: 57 TFLOP/s at 8, "
+                         "72 at 16, and an iteration's ~150 verification frames fill two full chunks)")
     ap.add_argument("--heuristic", choices=["owl", "yolo"], default="owl",
                     help="detector backend: owl = OWL-ViT-B/32 (configs[1], the headline); yolo = YOLO-World-v2-L on the f32 VALU, no "
                          "MFMA (BASELINE configs[3]; parity of that model is unpinned: its source is not in the reference tree)")
@@ -90,7 +97,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
     if args.lockstep <= 0:
-        args.lockstep = 8 if args.heuristic == "yolo" else 4
+        args.lockstep = 16 if args.heuristic == "yolo" else 4
     return args
 
 
@@ -371,7 +378,7 @@ def main():
     conc = max(1, min(args.concurrency, args.steps))
     if args.heuristic == "yolo":
         from tstar_amd.interface_heuristic import YoloWorldInterface
-        heuristics = [YoloWorldInterface(synthetic_seed=0, scale="l", max_batch=min(args.max_batch, 32), device=f"cuda:{local_rank}")
+        heuristics = [YoloWorldInterface(synthetic_seed=0, scale="l", max_batch=args.yolo_max_batch, device=f"cuda:{local_rank}")
                       for _ in range(conc)]
     else:
         heuristics = [OWLInterface(synthetic_seed=0, max_batch=args.max_batch, device=f"cuda:{local_rank}",
@@ -580,7 +587,7 @@ def main():
                 "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc, "lockstep_items_per_batch": max(1, min(args.lockstep, 31)),
                 "mean_search_latency_sec": latency, "single_search_alone_latency_sec": solo_latency,
                 "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,
-                "detector_images_per_video": images / args.steps, "max_batch": args.max_batch,
+                "detector_images_per_video": images / args.steps, "max_batch": args.yolo_max_batch if args.heuristic == "yolo" else args.max_batch,
                 "keyframes_rank0_step0": keys[0], "gathered_keyframe_rows": len(all_keys), "gathered_keyframes": all_keys,
                 "keyframes_verified": verified, "keyframes_verification": verify_detail,
                 # both ends of the timed region: marker kernels prof_mark_begin_kernel / prof_mark_end_kernel were enqueued on

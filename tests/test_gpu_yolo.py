@@ -102,10 +102,12 @@ def test_other_model_scales(scale):
     det.close()
 
 
-@pytest.mark.parametrize("scale,batch", [("s", 3), ("m", 2)])
+@pytest.mark.parametrize("scale,batch", [("s", 3), ("m", 2), ("s", 5)])
 def test_conv_kernels_bit_identical(scale, batch):
     """The VALU convolution kernels (LDS-tiled with 128- / 64-pixel tiles, scalar-weight with 8 / 4 pixels per lane, and its
-    halo-tile form for 3x3 layers) accumulate
+    halo-tile forms for 3x3 layers: 8 x 40 patches on the 160- / 80- / 40-wide maps, 16 x 20 patches over the row-stacked
+    batch on the 20-wide maps -- with batch 3 and 2 a patch spans two images there, the zero-row case -- each with 16 or 8
+    channels per wave) accumulate
     every output in the same fmaf order: a whole forward is BIT-identical whichever kernel the per-layer policy picks.
     The policy is read from the environment once per process, so each variant runs in its own interpreter.  Scale M has
     channel counts that are not multiples of 64 (48, 96, 192 ...): partially filled channel blocks."""
@@ -117,9 +119,11 @@ def test_conv_kernels_bit_identical(scale, batch):
     for name, env in [("tile128", {"TSTAR_YOLO_SW": "0", "TSTAR_YOLO_TM": "8", "TSTAR_YOLO_HALO": "0"}), ("tile64", {"TSTAR_YOLO_SW": "0", "TSTAR_YOLO_TM": "4", "TSTAR_YOLO_HALO": "0"}),
                       ("sw8", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "8", "TSTAR_YOLO_HALO": "0"}),
                       ("sw4", {"TSTAR_YOLO_SW": "1", "TSTAR_YOLO_SW_P": "4", "TSTAR_YOLO_HALO": "0"}),
-                      ("halo", {"TSTAR_YOLO_HALO": "2"}), ("policy", {})]:
+                      ("halo16", {"TSTAR_YOLO_HALO": "2", "TSTAR_YOLO_HALO_NCH": "16"}), ("halo8", {"TSTAR_YOLO_HALO": "2", "TSTAR_YOLO_HALO_NCH": "8"}),
+                      ("policy", {})]:
         e = dict(os.environ, **env)
-        for k in ("TSTAR_YOLO_SW", "TSTAR_YOLO_SW_P", "TSTAR_YOLO_SW_MIN", "TSTAR_YOLO_TM", "TSTAR_YOLO_TM_MIN", "TSTAR_YOLO_TN", "TSTAR_YOLO_HALO"):
+        for k in ("TSTAR_YOLO_SW", "TSTAR_YOLO_SW_P", "TSTAR_YOLO_SW_MIN", "TSTAR_YOLO_TM", "TSTAR_YOLO_TM_MIN", "TSTAR_YOLO_TN", "TSTAR_YOLO_HALO",
+                  "TSTAR_YOLO_HALO_NCH", "TSTAR_YOLO_HALO8_MAX", "TSTAR_YOLO_HALO8_MIN"):
             if k not in env:
                 e.pop(k, None)
         p = subprocess.run([sys.executable, probe, scale, str(batch)], env=e, capture_output=True, text=True, timeout=600)

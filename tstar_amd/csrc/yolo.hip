@@ -417,62 +417,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 
 }
 
 // ------------------------------------------------------------------ scalar-weight 3x3 conv with a halo tile
-// For 3x3 / stride-1 layers whose map is a multiple of 8 x 40 pixels (the 160-, 80- and 40-wide maps of a 640 x 640 input):
-// a workgroup owns an 8 x 40 patch of ONE image and stages its 10 x 42 halo patch of a 16-channel slice ONCE (9 DMA
-// instructions per wave, out-of-image pixels from the zero quad); the nine taps then read shifted windows of it -- every
-// shift is an immediate ds_read offset -- instead of re-loading a shifted tile per tap as conv_sw_kernel does: 6.5x fewer
-// DMA loads and two barriers per 144 k instead of one per 16.  Halo pixels are 80-byte rows (16 floats + one pad quad,
-// filled by a fifth dummy lane so that a DMA instruction still writes 1 KB contiguously): consecutive pixels at an
-// 80-byte stride make the ds_read_b128 of a 16-lane group conflict-free.  A lane owns 5 pixels x 16 channels (3 waves per
-// SIMD).  Same (ci slice, tap, k) fmaf order as every other conv kernel: bit-identical outputs.
-constexpr int HTH = 8, HTW = 40, HHW = HTW + 2, HNP = (HTH + 2) * HHW, HP = HTH * HTW / 64, HLD = SWK + 4;
-constexpr int HDMA = (HNP * 5 + 63) / 64;                           // DMA instructions per slice (33), 9 rounds of 4 waves
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_halo_kernel(ConvArgs a, int mt, int nt) {
-    __shared__ __attribute__((aligned(16))) float Hs[HDMA * 64 / 5 + 1][HLD];
+// For 3x3 / stride-1 layers: a workgroup owns a TH x TW patch of output pixels (320 of them: 8 x 40 on the 160-, 80- and
+// 40-wide maps of a 640 x 640 input, 16 x 20 on the 20-wide maps) and stages the patch's halo of a 16-channel slice ONCE
+// (9 DMA instructions per wave, out-of-image pixels from the zero quad); the nine taps then read shifted windows of it --
+// every shift is an immediate ds_read offset -- instead of re-loading a shifted tile per tap as conv_sw_kernel does: 6.5x
+// fewer DMA loads and two barriers per 144 k instead of one per 16.  Halo pixels are 80-byte rows (16 floats + one pad
+// quad, filled by a fifth dummy lane so that a DMA instruction still writes 1 KB contiguously): consecutive pixels at an
+// 80-byte stride make the ds_read_b128 of a 16-lane group conflict-free.  A lane owns 5 pixels x NCH channels.
+//
+// Patches are cut from the batch's images STACKED row-wise (row R = b * H + y; NHWC makes pixel (R, x) element R * W + x), so
+// a map whose height is not a multiple of TH (20 rows under 16-row patches) still tiles without ragged patches: a patch may
+// then span the boundary between two images, and the LDS halo gets ONE extra all-zero row at that boundary (XROW) -- it is the
+// bottom padding of the upper image and the top padding of the lower one at once; the output rows below it just sit one
+// halo row lower (a per-lane constant folded into the lane's base offset), so the tap loop is unchanged.
+//
+// NCH = 16 (3 waves per SIMD) is the form for layers with enough workgroups; NCH = 8 halves a wave's channel group (a
+// workgroup covers 32 channels: twice the workgroups, 40 accumulators: 4 waves per SIMD) for the small layers and small
+// batches, where 16-channel waves leave most SIMDs with one wave or none.  Same (ci slice, tap, k) fmaf order as every other
+// conv kernel: bit-identical outputs.
+constexpr int HLD = SWK + 4;
+template <int TH, int TW, bool XROW> struct HaloGeom {
+    static constexpr int HW2 = TW + 2, NROW = TH + 2 + (XROW ? 1 : 0), NP = NROW * HW2, P = TH * TW / 64;
+    static constexpr int NDMA = (NP * 5 + 63) / 64, NIT = (NDMA + 3) / 4, SLOTS = NDMA * 64 / 5 + 1;
+    static_assert(TH * TW % 64 == 0, "a halo patch is a whole number of pixels per lane");
+};
+template <int N> struct WRow;
+template <> struct WRow<16> { typedef f32x16 T; };
+template <> struct WRow<8> { typedef float T __attribute__((ext_vector_type(8))); };
+
+template <int TH, int TW, int NCH, bool XROW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 16 ? 3 : 4, NCH == 16 ? 3 : 4))) void conv_halo_kernel(ConvArgs a, int mt, int nt) {
+    using G = HaloGeom<TH, TW, XROW>;
+    constexpr int HW2 = G::HW2, HP = G::P, NIT = G::NIT, NDMA = G::NDMA, NC2 = NCH / 2;
+    __shared__ __attribute__((aligned(16))) float Hs[G::SLOTS][HLD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = xcd_remap(blockIdx.x, mt * nt);
-    const int cg0 = (tile % nt) * SWN + wave * 16;
+    const int cg0 = (tile % nt) * (4 * NCH) + wave * NCH;
     const bool active = cg0 < a.cout;
-    const int tpr = a.W / HTW, tpi = (a.H / HTH) * tpr;              // tiles per row / per image
-    const int pt = tile / nt, b = pt / tpi, y0 = ((pt % tpi) / tpr) * HTH, x0 = (pt % tpr) * HTW;
+    const int tpr = a.W / TW;
+    const int rows_total = a.M / a.W;                                 // B * H stacked rows
+    const int pt = tile / nt, row0 = (pt / tpr) * TH, x0 = (pt % tpr) * TW;
+    // image boundary strictly inside the patch (XROW only; the launcher guarantees H >= TH, so there is at most one):
+    // local row rb is the first row of the next image
+    int rb = 1 << 20;
+    if (XROW) {
+        const int rem = row0 % a.H;
+        if (rem != 0 && a.H - rem < TH) rb = a.H - rem;
+    }
+    const bool nb = XROW && rb < TH;
+    const int last = TH + 1 + (nb ? 1 : 0);                           // LDS row of the bottom halo
     // staging roles: DMA instruction i = wave + 4 it fills halo slots 64 i .. 64 i + 63; slot s = halo pixel s / 5, quad s % 5
-    constexpr int NIT = (HDMA + 3) / 4;
     unsigned hoff[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int sidx = (wave + 4 * it) * 64 + lane;
         const int hp = sidx / 5, q = sidx - hp * 5;
-        const int hy = hp / HHW, hx = hp - hy * HHW;
-        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-        const bool ok = hp < HNP && q < 4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        hoff[it] = ok ? 4u * (unsigned)(((b * a.H + iy) * a.W + ix) * a.src_ld + a.src_off + 4 * q) : 0xffffffffu;
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const int sr = row0 + hy - 1 - ((nb && hy > rb + 1) ? 1 : 0);  // stacked source row of LDS row hy
+        const int ix = x0 + hx - 1;
+        bool ok = hp < G::NP && q < 4 && hy <= last && ix >= 0 && ix < a.W && sr >= 0 && sr < rows_total;
+        if (nb && hy == rb + 1) ok = false;                            // the zero row between two images
+        if (hy == 0 && row0 % a.H == 0) ok = false;                    // top halo above an image's first row
+        if (hy == last && (row0 + TH) % a.H == 0) ok = false;          // bottom halo below an image's last row
+        hoff[it] = ok ? 4u * (unsigned)((sr * a.W + ix) * a.src_ld + a.src_off + 4 * q) : 0xffffffffu;
     }
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const unsigned zoffb = 4u * a.zoff;
     auto stage = [&](int ci0) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            if (wave + 4 * it < HDMA) {                                    // wave-uniform
+            if (wave + 4 * it < NDMA) {                                    // wave-uniform
                 const unsigned off = hoff[it] == 0xffffffffu ? zoffb : hoff[it] + 4u * (unsigned)ci0;
                 const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)&Hs[0][0]) + (unsigned)(wave + 4 * it) * 1024u;
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(a.src), "s"(la) : "memory");
             }
         }
     };
-    // compute roles: lane -> pixels p = lane + 64 j of the 8 x 40 patch; hb[j] = its top-left tap in the halo patch (floats)
+    // compute roles: lane -> pixels p = lane + 64 j of the patch; hb[j] = its top-left tap in the halo patch (floats)
     int hb[HP];
 #pragma unroll
     for (int j = 0; j < HP; ++j) {
-        const int p = lane + 64 * j, r = p / HTW, c = p - r * HTW;
-        hb[j] = (r * HHW + c) * HLD;
+        const int p = lane + 64 * j, r = p / TW, c = p - r * TW;
+        hb[j] = ((r + ((nb && r >= rb) ? 1 : 0)) * HW2 + c) * HLD;
     }
-    f32x2 acc[HP][8];
+    f32x2 acc[HP][NC2];
 #pragma unroll
     for (int j = 0; j < HP; ++j)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[j][c] = f32x2{0.f, 0.f};
-    typedef __attribute__((address_space(4))) const f32x16 cw16;
+        for (int c = 0; c < NC2; ++c) acc[j][c] = f32x2{0.f, 0.f};
+    typedef typename WRow<NCH>::T wrow_t;
+    typedef __attribute__((address_space(4))) const wrow_t cwrow;
     const float* wcol = a.wt + (active ? cg0 : 0);
     const float* hs = &Hs[0][0];
 
@@ -484,10 +519,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (!active) continue;
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int toff = (ky * HHW + kx) * HLD;                         // floats
+            const int toff = (ky * HW2 + kx) * HLD;                         // floats
             const float* wrow0 = wcol + (size_t)(tap * a.cin + ci0) * a.cout;
-            f32x16 wna = *(const cw16*)(unsigned long long)(wrow0);
-            f32x16 wnb = *(const cw16*)(unsigned long long)(wrow0 + a.cout);
+            wrow_t wna = *(cwrow*)(unsigned long long)(wrow0);
+            wrow_t wnb = *(cwrow*)(unsigned long long)(wrow0 + a.cout);
             f32x4 av[HP], an[HP];
 #pragma unroll
             for (int j = 0; j < HP; ++j) av[j] = *reinterpret_cast<const f32x4*>(hs + hb[j] + toff);
@@ -497,11 +532,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int kp = 0; kp < 2; ++kp) {
                     asm volatile("" :: "s"(wna[0]), "s"(wnb[0]));
                     __builtin_amdgcn_sched_barrier(0);
-                    const f32x16 wa = wna, wb = wnb;
+                    const wrow_t wa = wna, wb = wnb;
                     const int kn = kq * 4 + kp * 2 + 2;
                     if (kn < SWK) {
-                        wna = *(const cw16*)(unsigned long long)(wrow0 + (size_t)kn * a.cout);
-                        wnb = *(const cw16*)(unsigned long long)(wrow0 + (size_t)(kn + 1) * a.cout);
+                        wna = *(cwrow*)(unsigned long long)(wrow0 + (size_t)kn * a.cout);
+                        wnb = *(cwrow*)(unsigned long long)(wrow0 + (size_t)(kn + 1) * a.cout);
                     }
                     if (kp == 0 && kq < 3) {
 #pragma unroll
@@ -509,13 +544,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
+                    for (int c = 0; c < NC2; ++c) {
                         const f32x2 w2 = {wa[2 * c], wa[2 * c + 1]};
 #pragma unroll
                         for (int j = 0; j < HP; ++j) pkfma_lo(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
                     }
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
+                    for (int c = 0; c < NC2; ++c) {
                         const f32x2 w2 = {wb[2 * c], wb[2 * c + 1]};
 #pragma unroll
                         for (int j = 0; j < HP; ++j) pkfma_hi(acc[j][c], kp ? f32x2{av[j][2], av[j][3]} : f32x2{av[j][0], av[j][1]}, w2);
@@ -532,15 +567,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (!active) return;
     // epilogue (as conv_sw_epilogue, with the patch's pixel mapping)
     const int ch_per_head = a.mode == MODE_ATTN_MUL ? a.cout / a.heads : 1;
-    float bias[16];
+    float bias[NCH];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) bias[c] = a.bias ? a.bias[cg0 + c] : 0.f;
+    for (int c = 0; c < NCH; ++c) bias[c] = a.bias ? a.bias[cg0 + c] : 0.f;
 #pragma unroll
     for (int j = 0; j < HP; ++j) {
-        const int p = lane + 64 * j, r = p / HTW, c0 = p - r * HTW;
-        const size_t m = ((size_t)b * a.H + y0 + r) * a.W + x0 + c0;
+        const int p = lane + 64 * j, r = p / TW, c0 = p - r * TW;
+        if (row0 + r >= rows_total) continue;                              // ragged last patch of the stacked rows
+        const size_t m = (size_t)(row0 + r) * a.W + x0 + c0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NCH / 4; ++q) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -548,16 +584,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (a.act == YACT_SILU) t = silu(t);
                 v[e] = t;
             }
-            const int nb = cg0 + 4 * q;
+            const int nb4 = cg0 + 4 * q;
             if (a.mode == MODE_RESIDUAL) {
-                const f32x4 rr = *reinterpret_cast<const f32x4*>(a.aux + m * a.aux_ld + a.aux_off + nb);
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(a.aux + m * a.aux_ld + a.aux_off + nb4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += rr[e];
             } else if (a.mode == MODE_ATTN_MUL) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= a.aux[m * a.aux_ld + a.aux_off + (nb + e) / ch_per_head];
+                for (int e = 0; e < 4; ++e) v[e] *= a.aux[m * a.aux_ld + a.aux_off + (nb4 + e) / ch_per_head];
             }
-            *reinterpret_cast<f32x4*>(a.dst + m * a.dst_ld + a.dst_off + nb) = v;
+            *reinterpret_cast<f32x4*>(a.dst + m * a.dst_ld + a.dst_off + nb4) = v;
         }
     }
 }
@@ -661,18 +697,44 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const bool sw_ok = tiled && a.wt && a.cout % 16 == 0 && a.zoff != 0 && a.zoff < (1u << 30);   // byte offsets fit 32 bits
     static const int sw_min = [] { const char* e = getenv("TSTAR_YOLO_SW_MIN"); return e ? atoi(e) : 400; }();
     static const int sw_p_env = [] { const char* e = getenv("TSTAR_YOLO_SW_P"); return e ? atoi(e) : 0; }();
-    // halo form of the scalar-weight kernel for 3x3 / stride-1 layers on 8 x 40-divisible maps: from 320 workgroups up it beats
-    // both other kernels on every such layer (B = 32: 10-15 % per layer; B = 8: 221 vs 266 us at 320 workgroups, 445 vs 272
-    // at 160 -- profiles/r02_yolo_conv_halo_by_layer_b*.md)
+    // halo form of the scalar-weight kernel for 3x3 / stride-1 layers.  Patch 8 x 40 on maps that tile by it (the 160-, 80-
+    // and 40-wide ones), 16 x 20 over the row-stacked batch on 20-wide maps (H >= 16; one zero row at image boundaries).
+    // From 320 workgroups of 16-channel waves up that form beats both other kernels on every such layer (B = 32: 10-15 %
+    // per layer; B = 8: 221 vs 266 us at 320 workgroups, 445 vs 272 at 160 -- profiles/r02_yolo_conv_halo_by_layer_b*.md);
+    // below HALO8_MAX (600) such workgroups the 8-channel-per-wave form takes over (twice the workgroups, 4 waves per SIMD: the
+    // small maps and small batches, where 16-channel waves leave SIMDs empty), down to HALO8_MIN (600) of ITS workgroups: a
+    // halo workgroup walks all of K, so a launch that does not fill the chip once still lasts one workgroup's ~430 us (256
+    // input channels) and the tile kernel's many small workgroups win (B = 8, 40x40: 278 vs 426 us at 320 workgroups; B = 16,
+    // 640: 440 vs 543) -- thresholds from profiles/r03_yolo_halo_forms_by_layer_*.md.  TSTAR_YOLO_HALO = 0 never / 2 always (when eligible);
+    // TSTAR_YOLO_HALO_NCH = 8 / 16 forces the channel form.
     static const int halo_env = [] { const char* e = getenv("TSTAR_YOLO_HALO"); return e ? atoi(e) : -1; }();
-    const bool halo_ok = sw_ok && a.ks == 3 && a.stride == 1 && a.H % HTH == 0 && a.W % HTW == 0 && a.Ho == a.H && a.Wo == a.W;
-    const long long halo_wgs = halo_ok ? (long long)(a.M / (HTH * HTW)) * cdiv(a.cout, SWN) : 0;
-    if (halo_ok && (halo_env < 0 ? halo_wgs >= 320 : halo_env > 1)) {
-        const int B = a.M / (a.H * a.W);
-        const int mt = B * (a.H / HTH) * (a.W / HTW), nt = cdiv(a.cout, SWN);
+    static const int nch_env = [] { const char* e = getenv("TSTAR_YOLO_HALO_NCH"); return e ? atoi(e) : 0; }();
+    static const int halo8_max = [] { const char* e = getenv("TSTAR_YOLO_HALO8_MAX"); return e ? atoi(e) : 600; }();
+    static const int halo8_min = [] { const char* e = getenv("TSTAR_YOLO_HALO8_MIN"); return e ? atoi(e) : 600; }();
+    const bool halo_3x3 = sw_ok && a.ks == 3 && a.stride == 1 && a.Ho == a.H && a.Wo == a.W;
+    const bool halo_a = halo_3x3 && a.H % 8 == 0 && a.W % 40 == 0;                         // 8 x 40 patches, never across images
+    const bool halo_b = halo_3x3 && !halo_a && a.W % 20 == 0 && a.H >= 16;                  // 16 x 20 patches over stacked rows
+    const int rows_total = a.M / (a.W > 0 ? a.W : 1);
+    const long long halo_mt = halo_a ? (long long)(rows_total / 8) * (a.W / 40) : halo_b ? (long long)cdiv(rows_total, 16) * (a.W / 20) : 0;
+    const long long wgs16 = halo_mt * cdiv(a.cout, 64), wgs8 = halo_mt * cdiv(a.cout, 32);
+    int halo_nch = 0;                                                                       // 0 = not the halo form
+    if ((halo_a || halo_b) && halo_env != 0) {
+        if (nch_env == 8 || nch_env == 16) halo_nch = (halo_env > 1 || (nch_env == 16 ? wgs16 >= 320 : wgs8 >= halo8_min)) ? nch_env : 0;
+        else if (wgs16 >= halo8_max) halo_nch = 16;
+        else if (wgs8 >= halo8_min || halo_env > 1) halo_nch = 8;
+    }
+    if (halo_nch) {
+        const int mt = (int)halo_mt, nt = cdiv(a.cout, 4 * halo_nch);
         const bool prof = prof_enabled();
         if (prof) prof_start(PROF_CONV, s, 2.0 * a.M * a.cout * a.ks * a.ks * a.cin, conv_algorithmic_bytes(a));
-        hipLaunchKernelGGL(conv_halo_kernel, dim3(mt * nt), dim3(256), 0, s, a, mt, nt);
+        const dim3 grid(mt * nt);
+        if (halo_a) {
+            if (halo_nch == 16) hipLaunchKernelGGL((conv_halo_kernel<8, 40, 16, false>), grid, dim3(256), 0, s, a, mt, nt);
+            else hipLaunchKernelGGL((conv_halo_kernel<8, 40, 8, false>), grid, dim3(256), 0, s, a, mt, nt);
+        } else {
+            if (halo_nch == 16) hipLaunchKernelGGL((conv_halo_kernel<16, 20, 16, true>), grid, dim3(256), 0, s, a, mt, nt);
+            else hipLaunchKernelGGL((conv_halo_kernel<16, 20, 8, true>), grid, dim3(256), 0, s, a, mt, nt);
+        }
         if (prof) prof_stop(PROF_CONV, s);
     } else if (sw_ok && (sw_env < 0 ? sw_blocks >= sw_min : sw_env > 0)) {
         const int sw_p = sw_p_env ? sw_p_env : (sw_blocks >= 800 ? 4 : 8);
@@ -1453,6 +1515,10 @@ int tstar_yolo_detect(tstar_yolo* h, const uint8_t* d_images, int B, int H, int 
     // candidates exactly as mmyolo's predict_by_feat forms them (multi_label, score > score_thr = 0.001): the class-aware
     // NMS offsets depend on the largest coordinate among ALL of them, so the wrapper's 0.12 is not applied early
     const float cand_thr = YOLO_SCORE_THR;
+    // chunks of max_batch + one remainder.  Cutting a batch into near-equal chunks instead (156 -> 78 + 78 under a capacity of
+    // 96) was measured and is WORSE than 76 + 76 + 4 (bench conv average 98.3 vs 100.5 TFLOP/s): the chunk size is chosen so
+    // that the halo layers fill whole rounds of the chip's 768 workgroup slots (20 B workgroups on a 40x40 / 256-channel
+    // layer), and two images too many start a third, almost empty round on every such layer.
     for (int b0 = 0; b0 < B; b0 += h->max_batch) {
         const int Bc = (B - b0) < h->max_batch ? (B - b0) : h->max_batch;
         const uint8_t* imgs = d_images + (size_t)b0 * H * W * 3;
