@@ -24,6 +24,7 @@
 #include "heads.h"
 #include <math.h>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <vector>
 
@@ -243,6 +244,203 @@ struct SrcNV12 {
     static __device__ __forceinline__ size_t frame_bytes(int H, int W) { return (size_t)H * W * 3 / 2; }
 };
 
+// ------------------------------------------------------------------ RGB fast path of the two kernels below
+// The generic kernels (further down) spend ~500 executed instructions per output pixel, most of them overhead: three runtime integer
+// divisions for the index decode, 64-bit address arithmetic per tap, quarter-rate 32-bit multiplies (the compiler cannot
+// know the operands are small), byte extraction by shift / mask, two dependent levels of table loads.  For interleaved
+// RGB sources the same arithmetic (bit for bit: OpenCV's HResizeLinear / VResizeLinear fixed-point formulas) is restated
+// around what the hardware does in one instruction:
+//  * the host folds the index tables into one entry per output column / row (FUSED tables): per bilinear sample the BYTE
+//    offset of an 8-byte window inside the source row that holds both taps (clamped to the row: the last window ends at
+//    the row's last byte, so nothing is read outside the frame), a v_perm_b32 selector that drops the two taps' channel-0
+//    bytes into the halves of a dword (channels 1 / 2: selector + 0x00010001 / 0x00020002), the two 11-bit weights packed
+//    as u16 pairs, and row byte offsets for the vertical taps;
+//  * horizontal mix p0 * w0 + p1 * w1 = v_perm_b32 + v_dot2_u32_u16 per (row, channel);
+//  * vertical mix with v_mul_u32_u24 (full rate: operands are 12 and 15 bits) and SDWA word selects for the >> 16;
+//  * one frame per blockIdx.y (frame base in SGPRs, 32-bit per-lane offsets), pixel index -> (row, column) by a
+//    multiply-high with a host-computed reciprocal.
+// frames_to_grid: 8 window loads + ~190 full-rate VALU instructions per output pixel (16 taps x 3 channels through five
+// exact fixed-point mixes); bilinear_gather: 4 loads + ~55.  NV12 sources and degenerate sizes (W < 3) keep the generic kernels.
+struct FusedTab { uint4* d = nullptr; int n = 0; };
+static std::map<std::tuple<int, int, int, int, int>, FusedTab> g_fused;      // (kind, src, mid, dst, row pitch in bytes)
+
+static void fused_x_sample(const int4 t, int W, unsigned* off, unsigned* sel, unsigned* w) {
+    const int lim = 3 * W - 8;
+    const int o = 3 * t.x < lim ? 3 * t.x : lim;                       // window start (bytes into the row)
+    const unsigned oL = (unsigned)(3 * t.x - o), oR = (unsigned)(3 * t.y - o);
+    *off = (unsigned)o;
+    *sel = oL | 0x0C00u | (oR << 16) | 0x0C000000u;
+    *w = (unsigned)t.z | ((unsigned)t.w << 16);
+}
+
+// kind 0: X table of a single resize (src -> dst): one uint4 {off, sel, w, 0} per column
+// kind 1: Y table of a single resize: one uint4 {row0 bytes, row1 bytes, b0 << 12, b1 << 12} per row (row pitch = pitch bytes)
+// kind 2: X table of the two-step resize src -> mid -> dst: two uint4 {offA, selA, wA, offB} {selB, wB, wFinal, 0}
+// kind 3: Y table of the two-step resize: three uint4 {r0a, r0b, r1a, r1b} {A.b0, A.b1, B.b0, B.b1} {F.b0, F.b1, 0, 0} (weights << 12)
+static int get_fused(int kind, int src, int mid, int dst, int pitch, const uint4** out) {
+    std::vector<int4> h1, h2;
+    {   // host copies of the plain tables (same arithmetic as get_lintab)
+        auto build = [](int s_, int d_, std::vector<int4>& h) {
+            h.resize(d_);
+            const double scale = (double)s_ / d_;
+            for (int d = 0; d < d_; ++d) {
+                float f = (float)((d + 0.5) * scale - 0.5);
+                int s = (int)floorf(f);
+                f -= (float)s;
+                if (s < 0) { f = 0.f; s = 0; }
+                if (s >= s_ - 1) { f = 0.f; s = s_ - 1; }
+                const int s1 = s + 1 < s_ ? s + 1 : s_ - 1;
+                h[d] = make_int4(s, s1, sat_short(cv_round_half_even((1.f - f) * 2048.f)), sat_short(cv_round_half_even(f * 2048.f)));
+            }
+        };
+        std::lock_guard<std::mutex> lk(g_lintab_mu);
+        const auto key2 = std::make_tuple(kind, src, mid, dst, pitch);
+        auto it = g_fused.find(key2);
+        if (it == g_fused.end()) {
+            std::vector<uint4> h;
+            if (kind == 0 || kind == 1) {
+                build(src, dst, h1);
+                h.resize(dst);
+                for (int d = 0; d < dst; ++d) {
+                    if (kind == 0) { unsigned o, sl, w; fused_x_sample(h1[d], src, &o, &sl, &w); h[d] = make_uint4(o, sl, w, 0); }
+                    else h[d] = make_uint4((unsigned)h1[d].x * pitch, (unsigned)h1[d].y * pitch, (unsigned)h1[d].z << 12, (unsigned)h1[d].w << 12);
+                }
+            } else {
+                build(src, mid, h1);
+                build(mid, dst, h2);
+                const int per = kind == 2 ? 2 : 3;
+                h.resize((size_t)per * dst);
+                for (int d = 0; d < dst; ++d) {
+                    const int4 a = h1[h2[d].x], b = h1[h2[d].y];
+                    const unsigned wf = (unsigned)h2[d].z | ((unsigned)h2[d].w << 16);
+                    if (kind == 2) {
+                        unsigned oa, sa, wa, ob, sb, wb;
+                        fused_x_sample(a, src, &oa, &sa, &wa);
+                        fused_x_sample(b, src, &ob, &sb, &wb);
+                        h[2 * d] = make_uint4(oa, sa, wa, ob);
+                        h[2 * d + 1] = make_uint4(sb, wb, wf, 0);
+                    } else {
+                        h[3 * d] = make_uint4((unsigned)a.x * pitch, (unsigned)a.y * pitch, (unsigned)b.x * pitch, (unsigned)b.y * pitch);
+                        h[3 * d + 1] = make_uint4((unsigned)a.z << 12, (unsigned)a.w << 12, (unsigned)b.z << 12, (unsigned)b.w << 12);
+                        h[3 * d + 2] = make_uint4((unsigned)h2[d].z << 12, (unsigned)h2[d].w << 12, 0, 0);
+                    }
+                }
+            }
+            FusedTab t; t.n = (int)h.size();
+            TSTAR_HIP_CHECK(hipMalloc(&t.d, h.size() * sizeof(uint4)));
+            TSTAR_HIP_CHECK(hipMemcpy(t.d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice));
+            it = g_fused.emplace(key2, t).first;
+        }
+        *out = it->second.d;
+    }
+    return TSTAR_OK;
+}
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+// p0 * w0 + p1 * w1 for channel c of the two taps inside the 8-byte window {hi, lo}
+__device__ __forceinline__ unsigned hmix(unsigned hi, unsigned lo, unsigned sel, unsigned w) {
+    const unsigned pair = __builtin_amdgcn_perm(hi, lo, sel);
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, pair), __builtin_bit_cast(u16x2_t, w), 0u, false);
+}
+// VResizeLinear<uchar, int, short>: (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+// (b * (S >> 4)) >> 16 == ((b << 12) * (S & ~15)) >> 32 exactly (both factors are below 2^24), which is ONE full-rate
+// v_mul_hi_u32_u24 after one AND instead of shift + multiply + shift; the tables carry the weights pre-shifted (B = b << 12).
+__device__ __forceinline__ unsigned mulhi24(unsigned a, unsigned b) { unsigned d; asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ unsigned vmix(unsigned h0, unsigned h1, unsigned B0, unsigned B1) {
+    return (mulhi24(B0, h0 & ~15u) + mulhi24(B1, h1 & ~15u) + 2u) >> 2;
+}
+__device__ __forceinline__ uint64_t load_window(const uint8_t* p) { return reinterpret_cast<const PackedU64*>(p)->v; }
+
+// 12 output bytes of 4 consecutive pixels -> three aligned dword stores (rows are multiples of 4 pixels; byte stores of
+// single channels were the resize kernel's limiter: 3 strided store instructions per pixel)
+__device__ __forceinline__ void store_px4(uint8_t* d, const unsigned (&v)[4][3]) {
+    uint3 o;
+    o.x = v[0][0] | (v[0][1] << 8) | (v[0][2] << 16) | (v[1][0] << 24);
+    o.y = v[1][1] | (v[1][2] << 8) | (v[2][0] << 16) | (v[2][1] << 24);
+    o.z = v[2][2] | (v[3][0] << 8) | (v[3][1] << 16) | (v[3][2] << 24);
+    *reinterpret_cast<uint3*>(d) = o;
+}
+
+// PX output pixels of one row per lane (4 when the output width allows it, else 1)
+template <int PX>
+__global__ __launch_bounds__(256) void bilinear_gather_rgb_kernel(const uint8_t* __restrict__ video, size_t frame_bytes, const int* __restrict__ idx,
+                                                                  int ow, int owq, unsigned magic_owq, int nunits, const uint4* __restrict__ fx,
+                                                                  const uint4* __restrict__ fy, uint8_t* __restrict__ out) {
+    const unsigned u = blockIdx.x * 256u + threadIdx.x;               // unit = PX consecutive pixels of a row
+    if (u >= (unsigned)nunits) return;
+    const int i = blockIdx.y;
+    const uint8_t* f = video + (size_t)idx[i] * frame_bytes;          // wave-uniform
+    const unsigned oy = __umulhi(u, magic_owq), ox = (u - oy * (unsigned)owq) * PX;
+    const uint4 y = fy[oy];
+    const unsigned b0 = y.z, b1 = y.w;
+    uint4 x[PX];
+    uint64_t w0[PX], w1[PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) x[k] = fx[ox + k];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) { w0[k] = load_window(f + (size_t)(y.x + x[k].x)); w1[k] = load_window(f + (size_t)(y.y + x[k].x)); }
+    unsigned v[PX][3];
+#pragma unroll
+    for (int k = 0; k < PX; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned sel = x[k].y + 0x00010001u * c;
+            v[k][c] = vmix(hmix((unsigned)(w0[k] >> 32), (unsigned)w0[k], sel, x[k].z), hmix((unsigned)(w1[k] >> 32), (unsigned)w1[k], sel, x[k].z), b0, b1);
+        }
+    uint8_t* d = out + (((size_t)i * (nunits / owq) + oy) * ow + ox) * 3;
+    if constexpr (PX == 4) store_px4(d, v);
+    else { d[0] = (uint8_t)v[0][0]; d[1] = (uint8_t)v[0][1]; d[2] = (uint8_t)v[0][2]; }
+}
+
+template <int PX>
+__global__ __launch_bounds__(256) void frames_to_grid_rgb_kernel(const uint8_t* __restrict__ video, size_t frame_bytes, const int* __restrict__ idx,
+                                                                 int cols, int cw, int ch, int cwq, unsigned magic_cwq, const uint4* __restrict__ fx,
+                                                                 const uint4* __restrict__ fy, uint8_t* __restrict__ grid) {
+    const unsigned u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= (unsigned)(cwq * ch)) return;
+    const int i = blockIdx.y;
+    const uint8_t* f = video + (size_t)idx[i] * frame_bytes;          // wave-uniform
+    const unsigned oy = __umulhi(u, magic_cwq), ox = (u - oy * (unsigned)cwq) * PX;
+    const uint4 yr = fy[3 * oy], yw = fy[3 * oy + 1], yf = fy[3 * oy + 2];
+    const unsigned rows[4] = {yr.x, yr.y, yr.z, yr.w};               // r0a, r0b | r1a, r1b
+    const unsigned y0b0 = yw.x, y0b1 = yw.y, y1b0 = yw.z, y1b1 = yw.w, fyb0 = yf.x, fyb1 = yf.y;
+    unsigned v[PX][3];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const uint4 xa = fx[2 * (ox + k)], xb = fx[2 * (ox + k) + 1];
+        uint64_t wa[4], wb[4];                                         // windows: four source rows x columns (A, B)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { wa[r] = load_window(f + (size_t)(rows[r] + xa.x)); wb[r] = load_window(f + (size_t)(rows[r] + xa.w)); }   // SGPR base + 32-bit lane offset
+        const unsigned fxa = xb.z & 0xFFFFu, fxb = xb.z >> 16;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned sa = xa.y + 0x00010001u * c, sb = xb.x + 0x00010001u * c;
+            unsigned ha[4], hb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ha[r] = hmix((unsigned)(wa[r] >> 32), (unsigned)wa[r], sa, xa.z);
+                hb[r] = hmix((unsigned)(wb[r] >> 32), (unsigned)wb[r], sb, xb.y);
+            }
+            // the four samples of the intermediate image (u8 round trip, interface_searcher.py:362), then the 4 : 1 step (:186)
+            const unsigned p00 = vmix(ha[0], ha[1], y0b0, y0b1), p01 = vmix(hb[0], hb[1], y0b0, y0b1);
+            const unsigned p10 = vmix(ha[2], ha[3], y1b0, y1b1), p11 = vmix(hb[2], hb[3], y1b0, y1b1);
+            const unsigned h0 = __umul24(p00, fxa) + __umul24(p01, fxb), h1 = __umul24(p10, fxa) + __umul24(p11, fxb);
+            v[k][c] = vmix(h0, h1, fyb0, fyb1);
+        }
+    }
+    const int gr = i / cols, gc = i - gr * cols;
+    uint8_t* d = grid + (((size_t)gr * ch + oy) * ((size_t)cols * cw) + (size_t)gc * cw + ox) * 3;
+    if constexpr (PX == 4) store_px4(d, v);
+    else { d[0] = (uint8_t)v[0][0]; d[1] = (uint8_t)v[0][1]; d[2] = (uint8_t)v[0][2]; }
+}
+
+// TSTAR_INGEST_GENERIC=1 forces the generic kernels on RGB sources too (before / after counter runs, tools/pmc_ingest_counters.sh)
+static bool rgb_fast_ok(int W, long long npix, int div) {
+    static const bool generic = [] { const char* e = getenv("TSTAR_INGEST_GENERIC"); return e && atoi(e) != 0; }();
+    return !generic && W >= 3 && npix > 0 && npix * (long long)div < (1ll << 32) && npix < (1ll << 31);
+}
+static unsigned magic_of(int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+
 // one bilinear sample (all three channels) at output taps tx, ty
 template <class SRC>
 __device__ __forceinline__ Rgb lin_sample(const SRC& im, const int4 tx, const int4 ty) {
@@ -283,6 +481,19 @@ int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int
     const int4 *tx, *ty;
     int rc = get_lintab(W, ow, &tx); if (rc) return rc;
     rc = get_lintab(H, oh, &ty); if (rc) return rc;
+    if (!nv12 && n <= 65535 && rgb_fast_ok(W, (long long)ow * oh, ow) && (size_t)H * W * 3 < (1ull << 31)) {
+        const uint4 *fx, *fy;
+        rc = get_fused(0, W, 0, ow, 3 * W, &fx); if (rc) return rc;
+        rc = get_fused(1, H, 0, oh, 3 * W, &fy); if (rc) return rc;
+        // 4 pixels per lane need dword-aligned 12-byte stores: a row of the output must be a multiple of 4 pixels
+        const int px = (ow % 4 == 0 && (reinterpret_cast<size_t>(out) & 3) == 0) ? 4 : 1;
+        const int owq = ow / px, nunits = owq * oh;
+        const dim3 g((unsigned)((nunits + 255) / 256), (unsigned)n);
+        if (px == 4) hipLaunchKernelGGL(bilinear_gather_rgb_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
+        else hipLaunchKernelGGL(bilinear_gather_rgb_kernel<1>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
+        TSTAR_HIP_CHECK(hipGetLastError());
+        return TSTAR_OK;
+    }
     const size_t total = (size_t)n * ow * oh;
     const dim3 grid((unsigned)((total + 255) / 256));
     if (nv12) hipLaunchKernelGGL(bilinear_gather_kernel<SrcNV12>, grid, dim3(256), 0, s, video, H, W, d_idx, ow, oh, tx, ty, out, total);
@@ -329,6 +540,21 @@ int frames_to_grid_u8(const uint8_t* video, int H, int W, const int* d_idx, int 
     rc = get_lintab(H, 4 * ch, &t1y); if (rc) return rc;
     rc = get_lintab(4 * cw, cw, &t2x); if (rc) return rc;
     rc = get_lintab(4 * ch, ch, &t2y); if (rc) return rc;
+    if (!nv12 && rows * cols <= 65535 && rgb_fast_ok(W, (long long)cw * ch, cw) && (size_t)H * W * 3 < (1ull << 31)) {
+        const uint4 *fx, *fy;
+        rc = get_fused(2, W, 4 * cw, cw, 3 * W, &fx); if (rc) return rc;
+        rc = get_fused(3, H, 4 * ch, ch, 3 * W, &fy); if (rc) return rc;
+        // one pixel per lane here: four (12-byte stores) measured 63 us against 52 for the 256-frame grid -- 32 window loads
+        // and five dependent mix levels per lane leave too few lanes in flight; the grid's stores are 8 % of its bytes anyway
+        static const int px_env = [] { const char* e = getenv("TSTAR_GRID_PX"); return e ? atoi(e) : 1; }();
+        const int px = (px_env == 4 && cw % 4 == 0 && (reinterpret_cast<size_t>(grid) & 3) == 0) ? 4 : 1;
+        const int cwq = cw / px;
+        const dim3 g((unsigned)((cwq * ch + 255) / 256), (unsigned)(rows * cols));
+        if (px == 4) hipLaunchKernelGGL(frames_to_grid_rgb_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, cols, cw, ch, cwq, magic_of(cwq), fx, fy, grid);
+        else hipLaunchKernelGGL(frames_to_grid_rgb_kernel<1>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, cols, cw, ch, cwq, magic_of(cwq), fx, fy, grid);
+        TSTAR_HIP_CHECK(hipGetLastError());
+        return TSTAR_OK;
+    }
     const size_t total = (size_t)rows * cols * cw * ch;
     const dim3 g((unsigned)((total + 255) / 256));
     if (nv12) hipLaunchKernelGGL(frames_to_grid_kernel<SrcNV12>, g, dim3(256), 0, s, video, H, W, d_idx, cols, cw, ch, t1x, t1y, t2x, t2y, grid, total);
