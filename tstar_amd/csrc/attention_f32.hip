@@ -43,18 +43,16 @@
 //    tiles of a head on one L2: 119.8 -- the K/V re-reads already hit; 2-wave workgroups with 64 queries per wave (two Q
 //    fragments share every K / V fragment read: half the LDS fragment traffic per MFMA, 2 + 4 independent MFMA chains, 235
 //    VGPRs = 2 waves / SIMD): 114.7 vs 119.2 -- the LDS fragment reads are not the limiter either.
-//    Round 3, the one bounded experiment the review asked for (commit "attention: VALU straggler query"): the wave whose tile
-//    holds the single straggler query (T - 1 = 576) scores it with VALU ops from the K / V tiles the block stages anyway
-//    (32 FMAs + two 5-step wave reductions + 32 readlane/FMA per key tile; every lane of that wave already holds the query in
-//    fragment layout) instead of a 19th MFMA wave tile: 5.3 % fewer MFMAs.  Same-session A/B, three alternations:
-//    B = 256: 111.1 / 112.9 / 113.8 (round-2 kernel) vs 110.9 / 112.5 / 112.6; B = 64: 95.2 / 96.0 / 96.0 vs 98.0 / 97.8 / 97.9.
-//    No gain at the bench's batch size (gate was 125): removing MFMA work does not shorten anything, because the cost of
-//    T = 4 x 128 + 65 is SLOT occupancy -- the fifth workgroup of every head holds its CU slot (LDS, 4 wave slots) for all
-//    18 key tiles with two of its four waves working: 20 wave slots for 18.03 tiles of queries = the 0.90 already
-//    accounted for.  The 16x16x4 MFMA shape itself has the same rate (2048 flops / 32 cycles) and the same accumulator
-//    footprint per query as 32x32x2, so it buys registers only with fewer queries per wave, i.e. more K / V staging per
-//    MFMA (the 3- / 6-wave result above); what would recover the 10 % is a fifth workgroup that finishes in half the
-//    time (16 queries per wave there): a second loop body in this kernel for +0.9 % of a step -- not built.  Topic closed.
+//    Round 3.  (a) The wave whose tile holds the single straggler query (T - 1 = 576) scoring it with VALU ops from the staged
+//    K / V tiles instead of a 19th MFMA wave tile (5.3 % fewer MFMAs): same-session A/B at B = 256 111.1 / 112.9 / 113.8
+//    (round-2 kernel) vs 110.9 / 112.5 / 112.6, B = 64 +2 % -- not adopted on its own.  (b) ADOPTED: the last query block of a
+//    head (65 queries at T = 577) as FOUR 16-query wave tiles on v_mfma_f32_16x16x4_f32 plus the straggler shared by the four
+//    waves as VALU work (attention_tail16 below), dispatched after all full blocks: B = 256 119.5 / 119.8 / 119.9 -> 123.3 /
+//    124.0 / 123.8 TFLOP/s (+3.4 %), B = 64 105.6 -> 109.5, B = 16 90 -> 95 (profiles/r03_attention_tail16_ab.md).  The review's
+//    gate of 125 is not met: the gain is the 5 % of MFMA work the idle / single-query wave tiles of that block used to issue plus
+//    part of their slot occupancy; the 16x16x4 shape has the same rate and the same accumulator footprint per query as 32x32x2,
+//    so it buys nothing by itself.  What remains between 124 and the 136-140 of a register-only MFMA loop is per-wave
+//    serialisation (LDS fragment reads and the softmax between dependent MFMA chains) under 4 waves per SIMD.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -68,7 +66,224 @@ constexpr int HD = 64, KB = 32;
 // must hit 16 distinct 16-B slots, and the S^T fragment read (16 keys with distinct k & 15, one logical column) does.
 __device__ __forceinline__ int kswz(int key, int j) { return (j ^ (key & 15)) * 4; }
 
-template <int MODE>
+// ---------------------------------------------------------------------------------------------
+// The last query block of a head when T = 128 n + 65 (577 = 4 x 128 + 64 + 1): with 32-query wave tiles that workgroup
+// keeps its CU slot (LDS, four wave slots) for all 18 key tiles while two of its waves work, the third carries ONE query
+// and the fourth none -- 20 wave slots for 18.03 tiles of queries.  Here the same 65 queries are spread over all four waves
+// as 16-query tiles on v_mfma_f32_16x16x4_f32 (same rate per flop, half the MFMAs per wave and key tile, so the workgroup is
+// done in roughly half the time), and the straggler query T-1 is scored by wave 3 with VALU ops from the K / V tiles the
+// workgroup stages anyway.  These short workgroups are dispatched AFTER all full ones (block index order), so they fill the tail.
+// Layouts (16x16x4: A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15], C/D: n = lane & 15, m = 4 (lane >> 4) + r):
+//   S^T tile kt (keys 16 kt .. +15): A = K[key = lane & 15][d = 16 j + 4 g + e] (one swizzled ds_read_b128 per j), B = Q fragment;
+//   a lane ends up with the scores of query lane & 15 against keys 16 kt + 4 g + r -- which is exactly the B operand
+//   P[key][q] of O^T += V^T P^T at step (kt, r), as in the 32-query form; softmax statistics need two cross-lane steps (g).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// V rows are rotated by 16 ((key >> 2) & 3) floats in the short workgroups: the PV fragment read of a 32-lane service group
+// spans two key rows 4 apart (g = 0 / 1), which would otherwise sit on the same 16 banks
+__device__ __forceinline__ int vrot(int key) { return 16 * ((key >> 2) & 3); }
+__device__ __forceinline__ void attention_tail16(const float* __restrict__ qkv, float* __restrict__ out, int T, int heads, int b, int head,
+                                              float (&Ks)[2][32][64], float (&Vs)[2][32][64]) {
+    const int D = heads * HD, D3 = 3 * D;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const size_t rowbase = (size_t)b * T;
+    const int q = (T - 65) + wave * 16 + l15;                          // 64 full queries; all valid
+    const float sc = 0.125f * 1.44269504088896340736f;
+    f32x4 qf[4];
+    {
+        const float* qp = qkv + (rowbase + q) * D3 + head * HD + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { qf[j] = *reinterpret_cast<const f32x4*>(qp + 16 * j); qf[j] *= sc; }
+    }
+    // The straggler query T-1 is shared by the four waves: wave w scores it against keys 8 w .. 8 w + 7 of every tile with VALU
+    // ops (lane = (key k8, 8-dim group dg)) and keeps its own online-softmax state over THOSE keys; the four partial states are
+    // merged once at the end.  Per tile and wave: 8 FMAs + three 3-step reductions + 8 x (readlane, ds_read, FMA).
+    const int k8 = lane >> 3, dg = lane & 7;
+    f32x4 qs[2];
+    {
+        const float* qp = qkv + (rowbase + T - 1) * D3 + head * HD + 8 * dg;
+        qs[0] = *reinterpret_cast<const f32x4*>(qp); qs[1] = *reinterpret_cast<const f32x4*>(qp + 4);
+        qs[0] *= sc; qs[1] *= sc;
+    }
+    float mv_run = -INFINITY, lv_run = 0.f, o_v = 0.f;
+
+    const int f4 = t & 15, sr = t >> 4;
+    const float* kbase = qkv + D + head * HD + f4 * 4;
+    const float* vbase = qkv + 2 * D + head * HD + f4 * 4;
+    const int nkb = T / KB;                                            // T = 32 n + 1: the last key is folded in after the loop
+    f32x4 rk[2], rv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const size_t ro = (rowbase + sr + 16 * i) * D3;
+        rk[i] = *reinterpret_cast<const f32x4*>(kbase + ro);
+        rv[i] = *reinterpret_cast<const f32x4*>(vbase + ro);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<f32x4*>(&Ks[0][sr + 16 * i][kswz(sr + 16 * i, f4)]) = rk[i];
+        *reinterpret_cast<f32x4*>(&Vs[0][sr + 16 * i][(f4 * 4 + vrot(sr + 16 * i)) & 63]) = rv[i];
+    }
+    __syncthreads();
+
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    int cur = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const bool more = kb + 1 < nkb;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const size_t ro = (rowbase + (kb + 1) * KB + sr + 16 * i) * D3;
+                rk[i] = *reinterpret_cast<const f32x4*>(kbase + ro);
+                rv[i] = *reinterpret_cast<const f32x4*>(vbase + ro);
+            }
+        }
+        f32x4_t s[2];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const float* kp = &Ks[cur][16 * kt + l15][0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(kp + (((4 * j + g) ^ l15) * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[e], qf[j][e], s[kt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // the wave's share of the straggler query: keys 8 wave + k8 of this tile (issued here so that it overlaps the MFMA chain)
+        float sx;
+        {
+            const int key = 8 * wave + k8;
+            const float* kp = &Ks[cur][key][0];
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + kswz(key, 2 * dg));
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + kswz(key, 2 * dg + 1));
+            sx = k0[0] * qs[0][0];
+            sx = fmaf(k0[1], qs[0][1], sx); sx = fmaf(k0[2], qs[0][2], sx); sx = fmaf(k0[3], qs[0][3], sx);
+            sx = fmaf(k1[0], qs[1][0], sx); sx = fmaf(k1[1], qs[1][1], sx); sx = fmaf(k1[2], qs[1][2], sx); sx = fmaf(k1[3], qs[1][3], sx);
+            sx += __shfl_xor(sx, 1); sx += __shfl_xor(sx, 2); sx += __shfl_xor(sx, 4);      // all 8 lanes of key k8 hold its score
+        }
+        float mb = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        mb = fmaxf(mb, __shfl_xor(mb, 16));
+        mb = fmaxf(mb, __shfl_xor(mb, 32));
+        const float m_new = fmaxf(m_run, mb);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // exp2(-inf) = 0 on the first tile
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_new); ps += s[kt][r]; }
+        ps += __shfl_xor(ps, 16);
+        ps += __shfl_xor(ps, 32);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kt + 4 * g + r;
+                const float* vrow = &Vs[cur][key][0];
+                const int c0 = l15 + vrot(key);                        // vrot is a multiple of 16: (c0 + 16 dt) & 63 keeps the lane's column
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[(c0 + 16 * dt) & 63], s[kt][r], o[dt], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        {
+            // online softmax of the straggler over this wave's 8 keys, then O[d = lane] += sum_k p_k V[k][lane]
+            float mx = sx;
+            mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(mv_run, mx);
+            const float al = __builtin_amdgcn_exp2f(mv_run - mn);
+            const float p = __builtin_amdgcn_exp2f(sx - mn);
+            float pv = p;
+            pv += __shfl_xor(pv, 8); pv += __shfl_xor(pv, 16); pv += __shfl_xor(pv, 32);
+            lv_run = lv_run * al + pv;
+            mv_run = mn;
+            o_v *= al;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int key = 8 * wave + k;
+                const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 8 * k));     // lane 8 k holds key k's p
+                o_v = fmaf(pk, Vs[cur][key][(lane + vrot(key)) & 63], o_v);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<f32x4*>(&Ks[cur ^ 1][sr + 16 * i][kswz(sr + 16 * i, f4)]) = rk[i];
+                *reinterpret_cast<f32x4*>(&Vs[cur ^ 1][sr + 16 * i][(f4 * 4 + vrot(sr + 16 * i)) & 63]) = rv[i];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // the straggler KEY T-1 for the 16 queries of this wave: the lane holds a quarter of its query's 64 dims
+    const size_t ro = (rowbase + (T - 1)) * D3 + head * HD;
+    {
+        float sx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(qkv + ro + D + 16 * j + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sx += kv[e] * qf[j][e];
+        }
+        sx += __shfl_xor(sx, 16);
+        sx += __shfl_xor(sx, 32);
+        const float m_new = fmaxf(m_run, sx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float p = __builtin_amdgcn_exp2f(sx - m_new);
+        l_run = l_run * alpha + p;
+        const float inv = 1.0f / l_run;
+        float* op = out + (rowbase + q) * D + head * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(qkv + ro + 2 * D + 16 * dt + 4 * g);
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (o[dt][e] * alpha + p * vv[e]) * inv;
+            *reinterpret_cast<f32x4*>(op + 16 * dt) = a;
+        }
+    }
+    // merge the four waves' partial states of the straggler query (through the K tile buffer, free now), add key T-1, store
+    float* mrg = &Ks[0][0][0];                                         // [4][66]: o[64], m, l per wave
+    __syncthreads();
+    mrg[wave * 66 + lane] = o_v;
+    if (lane == 0) { mrg[wave * 66 + 64] = mv_run; mrg[wave * 66 + 65] = lv_run; }
+    __syncthreads();
+    if (wave == 0) {
+        float sx = 0.f;                                                // score of key T-1: lane (k8 unused) -> 8-dim group dg
+        {
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(qkv + ro + D + 8 * dg);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(qkv + ro + D + 8 * dg + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sx = fmaf(k0[e], qs[0][e], sx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sx = fmaf(k1[e], qs[1][e], sx);
+            sx += __shfl_xor(sx, 1); sx += __shfl_xor(sx, 2); sx += __shfl_xor(sx, 4);
+        }
+        float m = sx;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m = fmaxf(m, mrg[w * 66 + 64]);
+        float l = __builtin_amdgcn_exp2f(sx - m), ov = l * qkv[ro + 2 * D + lane];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __builtin_amdgcn_exp2f(mrg[w * 66 + 64] - m);
+            l = fmaf(mrg[w * 66 + 65], f, l);
+            ov = fmaf(mrg[w * 66 + lane], f, ov);
+        }
+        out[(rowbase + T - 1) * D + head * HD + lane] = ov / l;
+    }
+}
+
+template <int MODE, bool T16 = false>
 __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int T, int heads, int qtiles,
                                                             const uint8_t* __restrict__ key_mask) {
@@ -76,8 +291,19 @@ __global__ __launch_bounds__(256, 4) void attention_f32_kernel(const float* __re
     __shared__ __attribute__((aligned(16))) float Vs[2][KB][HD];
 
     const int D = heads * HD, D3 = 3 * D;
-    int bid = blockIdx.x;
-    const int qt = bid % qtiles; bid /= qtiles;
+    int bid = blockIdx.x, qt;
+    if (T16) {
+        // all full 128-query blocks first, then one short block per (image, head): the short ones fill the tail
+        const int n_full = (gridDim.x / qtiles) * (qtiles - 1);
+        if (bid >= n_full) {
+            bid -= n_full;
+            attention_tail16(qkv, out, T, heads, bid / heads, bid % heads, Ks, Vs);
+            return;
+        }
+        qt = bid % (qtiles - 1); bid /= (qtiles - 1);
+    } else {
+        qt = bid % qtiles; bid /= qtiles;
+    }
     const int head = bid % heads;
     const int b = bid / heads;
 
@@ -264,7 +490,11 @@ int attention_f32(const float* qkv, float* out, int B, int T, int heads, int mod
     const int grid = B * heads * qtiles;
     const bool prof = prof_enabled();
     if (prof) prof_start(PROF_ATTN, s, 4.0 * B * heads * (double)T * T * HD);
-    if (mode == 0)
+    // TSTAR_ATTN_T16=0 runs the round-2 form (the last 65 queries of a head as 32-query wave tiles) for same-session A/Bs
+    static const bool t16 = [] { const char* e = getenv("TSTAR_ATTN_T16"); return e ? atoi(e) != 0 : true; }();
+    if (mode == 0 && t16 && T % 128 == 65)
+        hipLaunchKernelGGL((attention_f32_kernel<0, true>), dim3(grid), dim3(256), 0, s, qkv, out, T, heads, qtiles, key_mask);
+    else if (mode == 0)
         hipLaunchKernelGGL(attention_f32_kernel<0>, dim3(grid), dim3(256), 0, s, qkv, out, T, heads, qtiles, key_mask);
     else
         hipLaunchKernelGGL(attention_f32_kernel<1>, dim3(grid), dim3(256), 0, s, qkv, out, T, heads, qtiles, key_mask);
