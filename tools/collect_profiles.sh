@@ -18,6 +18,7 @@ PY="python $ROOT/bench.py"
 $PY --steps 16 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
 $PY --steps 4 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
+$PY --steps 4 --warmup 1 --weights bf16_exact --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5_exact_split.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --workload haystack --no-cpu-baseline > "$OUT/${TAG}_bench_haystack_1gpu.json" 2>> "$OUT/bench.err"
 $PY --workload haystack32 --no-cpu-baseline > "$OUT/${TAG}_bench_haystack32_1gpu.json" 2>> "$OUT/bench.err"
@@ -48,7 +49,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_IN
     rm -rf /tmp/prof_$N
     # --no-grid4 --no-verify: every GEMM dispatch of the run is one of the timed steps' (plus the text tower's 48 tiny ones),
     # so the per-launch averages are over the same population as the bench line's avg_launch_gflop
-    rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify > /dev/null 2> "$OUT/rocprof_$N.err"
+    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify > /dev/null 2> "$OUT/rocprof_$N.err"
 done
 F=$(find /tmp/prof_FETCH_SIZE -name '*.db' | head -1)
 W=$(find /tmp/prof_WRITE_SIZE -name '*.db' | head -1)
@@ -72,5 +73,8 @@ python $ROOT/tools/bench_gemm_cfg.py > "$OUT/${TAG}_gemm_tile_configs.log" 2>&1
 python $ROOT/tools/sweep_small_m.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_gemm_subwave_sweep.log"
 python $ROOT/tools/bench_kernels.py > "$OUT/${TAG}_kernel_microbench.log" 2>&1
 python $ROOT/tools/bench_ingest.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_ingest_bandwidth.log"
+python $ROOT/tools/bench_gemm_bf16.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_gemm_bf16_tiles.log"
+python $ROOT/tools/bench_attention.py 16 64 256 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_attention_microbench.log"
+[ -x $ROOT/tools/lab/valu_int_rate ] && $ROOT/tools/lab/valu_int_rate > "$OUT/${TAG}_valu_int_issue_rate.log" 2>&1
 ls -la "$OUT"
 exit ${FAILED:-0}
