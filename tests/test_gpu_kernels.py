@@ -278,8 +278,11 @@ def _attn_ref(qkv, B, T, heads, mask=None):
     return torch.matmul(att, v).transpose(1, 2).reshape(B * T, D)
 
 
-@pytest.mark.parametrize("B,T,heads", [(1, 577, 12), (2, 577, 12), (3, 16, 8), (1, 33, 2), (1, 128, 1), (1, 1, 1), (2, 97, 3), (1, 600, 2)])
+@pytest.mark.parametrize("B,T,heads", [(1, 577, 12), (2, 577, 12), (3, 16, 8), (1, 33, 2), (1, 128, 1), (1, 1, 1), (2, 97, 3), (1, 600, 2),
+                                       (1, 65, 2), (3, 193, 4), (2, 321, 1), (5, 577, 3)])
 def test_attention_full(lib, B, T, heads):
+    # T = 128 n + 65 (65, 193, 321, 577) takes the 16-query tail workgroup for the last 65 queries of every (image, head):
+    # short workgroups after all full ones, four waves x 16 queries + the straggler query T-1 shared as VALU work
     g = torch.Generator().manual_seed(B * 1000 + T + heads)
     D = heads * 64
     qkv = torch.randn(B * T, 3 * D, generator=g)
@@ -304,6 +307,11 @@ def test_attention_spiked_scores(lib, last_key_spike):
     qkv[3, D:2 * D] *= 25.0          # and an early big one
     if last_key_spike:
         qkv[576, D:2 * D] *= 60.0
+    # the straggler QUERY 576 with one dominant key in each of two different waves' key shares (keys 8 w .. 8 w + 7 of a tile):
+    # its four partial online-softmax states differ by hundreds of exponent units when they are merged
+    qkv[576, :D] *= 6.0
+    qkv[101, D:2 * D] *= 30.0
+    qkv[250, D:2 * D] *= 18.0
     ref = _attn_ref(qkv, B, T, heads)
     out = torch.empty((B * T, D), device="cuda")
     dqkv = qkv.cuda()
