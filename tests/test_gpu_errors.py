@@ -106,3 +106,31 @@ def test_kernel_entry_point_validation(env):
     assert lib.tstar_ssim_pairwise(None, 1, None, 1, 4, 4, None, None, None) == 1
     n = C.c_longlong(); ms = C.c_double(); fl = C.c_double()
     assert lib.tstar_prof_read(7, C.byref(n), C.byref(ms), C.byref(fl)) == 1
+
+
+def test_round3_entry_points_validate_their_arguments(env):
+    """The entries added in round 3: marker kernels, algorithmic-byte counters, prepared-weights bf16 GEMM, RCCL availability."""
+    L, lib, h = env
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tstar_prof_mark(2, st) == 1 and b"0 (begin) or 1 (end)" in lib.tstar_last_error()
+    assert lib.tstar_prof_mark(0, st) == 0 and lib.tstar_prof_mark(1, st) == 0
+    by = C.c_double(-1.0)
+    assert lib.tstar_prof_read_bytes(7, C.byref(by)) == 1
+    L.check(lib.tstar_prof_enable(1))
+    A = torch.randn(256, 64, device="cuda")
+    Wb = torch.randn(128, 64, device="cuda").to(torch.bfloat16)
+    Cc = torch.empty(256, 128, device="cuda")
+    assert lib.tstar_gemm_bf16w_pre(A.data_ptr(), Wb.data_ptr(), Cc.data_ptr(), None, None, 256, 128, 64, 0, 4, -1, st) == 1     # a_terms 2 or 3
+    assert lib.tstar_gemm_bf16w_pre(A.data_ptr(), Wb.data_ptr(), Cc.data_ptr(), None, None, 256, 100, 64, 0, 2, -1, st) == 1     # N % 128
+    L.check(lib.tstar_gemm_bf16w_pre(A.data_ptr(), Wb.data_ptr(), Cc.data_ptr(), None, None, 256, 128, 64, 0, 2, -1, st))
+    L.check(lib.tstar_gemm_bf16w_pre(A.data_ptr(), Wb.data_ptr(), Cc.data_ptr(), None, None, 256, 128, 64, 0, 3, -1, st))
+    torch.cuda.synchronize()
+    ref = A.double() @ Wb.double().t()
+    assert (Cc.double() - ref).abs().max().item() < 1e-4
+    n, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
+    L.check(lib.tstar_prof_read(0, C.byref(n), C.byref(ms), C.byref(fl)))
+    L.check(lib.tstar_prof_read_bytes(0, C.byref(by)))
+    L.check(lib.tstar_prof_enable(0))
+    assert n.value == 2 and fl.value == 2 * 2.0 * 256 * 128 * 64
+    assert by.value == 2 * (4.0 * 256 * 64 + 2.0 * 128 * 64 + 4.0 * 256 * 128)            # A (f32) + W (bf16) + C, per launch
+    assert lib.tstar_comm_available() == 0                                                # torch's RCCL is loadable on a GPU box
