@@ -392,6 +392,38 @@ __global__ __launch_bounds__(256) void bilinear_gather_rgb_kernel(const uint8_t*
     else { d[0] = (uint8_t)v[0][0]; d[1] = (uint8_t)v[0][1]; d[2] = (uint8_t)v[0][2]; }
 }
 
+// one output pixel of the grid: 8 (or, when the two intermediate rows share their middle source row, 6) window loads, the
+// horizontal mixes of the four source rows at the two sample columns, the four samples of the intermediate image (u8 round
+// trip, interface_searcher.py:362), then the 4 : 1 step (:186)
+template <bool DUP>
+__device__ __forceinline__ void grid_pixel(const uint8_t* f, const uint4 yr, const uint4 yw, const uint4 yf, const uint4 xa, const uint4 xb,
+                                           unsigned (&v)[3]) {
+    const unsigned rows[4] = {yr.x, yr.y, yr.z, yr.w};               // r0a, r0b | r1a, r1b   (DUP: r1a == r0b)
+    uint64_t wa[4], wb[4];                                             // windows: four source rows x columns (A, B)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (DUP && r == 2) { wa[2] = wa[1]; wb[2] = wb[1]; continue; }
+        wa[r] = load_window(f + (size_t)(rows[r] + xa.x));             // SGPR base + 32-bit lane offset
+        wb[r] = load_window(f + (size_t)(rows[r] + xa.w));
+    }
+    const unsigned fxa = xb.z & 0xFFFFu, fxb = xb.z >> 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned sa = xa.y + 0x00010001u * c, sb = xb.x + 0x00010001u * c;
+        unsigned ha[4], hb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (DUP && r == 2) { ha[2] = ha[1]; hb[2] = hb[1]; continue; }
+            ha[r] = hmix((unsigned)(wa[r] >> 32), (unsigned)wa[r], sa, xa.z);
+            hb[r] = hmix((unsigned)(wb[r] >> 32), (unsigned)wb[r], sb, xb.y);
+        }
+        const unsigned p00 = vmix(ha[0], ha[1], yw.x, yw.y), p01 = vmix(hb[0], hb[1], yw.x, yw.y);
+        const unsigned p10 = vmix(ha[2], ha[3], yw.z, yw.w), p11 = vmix(hb[2], hb[3], yw.z, yw.w);
+        const unsigned h0 = __umul24(p00, fxa) + __umul24(p01, fxb), h1 = __umul24(p10, fxa) + __umul24(p11, fxb);
+        v[c] = vmix(h0, h1, yf.x, yf.y);
+    }
+}
+
 template <int PX>
 __global__ __launch_bounds__(256) void frames_to_grid_rgb_kernel(const uint8_t* __restrict__ video, size_t frame_bytes, const int* __restrict__ idx,
                                                                  int cols, int cw, int ch, int cwq, unsigned magic_cwq, const uint4* __restrict__ fx,
@@ -401,32 +433,22 @@ __global__ __launch_bounds__(256) void frames_to_grid_rgb_kernel(const uint8_t* 
     const int i = blockIdx.y;
     const uint8_t* f = video + (size_t)idx[i] * frame_bytes;          // wave-uniform
     const unsigned oy = __umulhi(u, magic_cwq), ox = (u - oy * (unsigned)cwq) * PX;
-    const uint4 yr = fy[3 * oy], yw = fy[3 * oy + 1], yf = fy[3 * oy + 2];
-    const unsigned rows[4] = {yr.x, yr.y, yr.z, yr.w};               // r0a, r0b | r1a, r1b
-    const unsigned y0b0 = yw.x, y0b1 = yw.y, y1b0 = yw.z, y1b1 = yw.w, fyb0 = yf.x, fyb1 = yf.y;
     unsigned v[PX][3];
+    // A wave covers 64 consecutive pixels of a 200-wide cell row: two waves in three lie inside ONE output row.  Their row
+    // table entry then comes through the scalar cache (three s_load_dwordx4 instead of three vector loads per lane), and
+    // whether the two intermediate rows share their middle source row -- they do on ~95 % of the rows of a 360 -> 380 -> 95
+    // resize -- is a scalar branch that drops two of the eight window loads and a quarter of the horizontal mixes.
+    const unsigned oy_u = __builtin_amdgcn_readfirstlane(oy);
+    if (PX == 1 && __all(oy == oy_u)) {
+        const uint4* q = fy + 3 * oy_u;
+        const uint4 yr = q[0], yw = q[1], yf = q[2];
+        const uint4 xa = fx[2 * ox], xb = fx[2 * ox + 1];
+        if (yr.y == yr.z) grid_pixel<true>(f, yr, yw, yf, xa, xb, v[0]);
+        else grid_pixel<false>(f, yr, yw, yf, xa, xb, v[0]);
+    } else {
+        const uint4 yr = fy[3 * oy], yw = fy[3 * oy + 1], yf = fy[3 * oy + 2];
 #pragma unroll
-    for (int k = 0; k < PX; ++k) {
-        const uint4 xa = fx[2 * (ox + k)], xb = fx[2 * (ox + k) + 1];
-        uint64_t wa[4], wb[4];                                         // windows: four source rows x columns (A, B)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { wa[r] = load_window(f + (size_t)(rows[r] + xa.x)); wb[r] = load_window(f + (size_t)(rows[r] + xa.w)); }   // SGPR base + 32-bit lane offset
-        const unsigned fxa = xb.z & 0xFFFFu, fxb = xb.z >> 16;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const unsigned sa = xa.y + 0x00010001u * c, sb = xb.x + 0x00010001u * c;
-            unsigned ha[4], hb[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ha[r] = hmix((unsigned)(wa[r] >> 32), (unsigned)wa[r], sa, xa.z);
-                hb[r] = hmix((unsigned)(wb[r] >> 32), (unsigned)wb[r], sb, xb.y);
-            }
-            // the four samples of the intermediate image (u8 round trip, interface_searcher.py:362), then the 4 : 1 step (:186)
-            const unsigned p00 = vmix(ha[0], ha[1], y0b0, y0b1), p01 = vmix(hb[0], hb[1], y0b0, y0b1);
-            const unsigned p10 = vmix(ha[2], ha[3], y1b0, y1b1), p11 = vmix(hb[2], hb[3], y1b0, y1b1);
-            const unsigned h0 = __umul24(p00, fxa) + __umul24(p01, fxb), h1 = __umul24(p10, fxa) + __umul24(p11, fxb);
-            v[k][c] = vmix(h0, h1, fyb0, fyb1);
-        }
+        for (int k = 0; k < PX; ++k) grid_pixel<false>(f, yr, yw, yf, fx[2 * (ox + k)], fx[2 * (ox + k) + 1], v[k]);
     }
     const int gr = i / cols, gc = i - gr * cols;
     uint8_t* d = grid + (((size_t)gr * ch + oy) * ((size_t)cols * cw) + (size_t)gc * cw + ox) * 3;
