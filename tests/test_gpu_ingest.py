@@ -88,6 +88,35 @@ def test_nv12_store_matches_rgb_of_converted_frames():
     assert np.array_equal(out[1].cpu().numpy(), R.cv_bilinear_resize(rgb[1], 600, 285))
 
 
+@pytest.mark.parametrize("H,W,g", [(360, 640, 4), (72, 128, 3), (90, 160, 1), (480, 854, 2), (36, 4, 2), (1080, 1920, 2)])
+def test_nv12_grid_random_full_range(H, W, g):
+    """NV12 grid ingest on FULL-RANGE random bytes (the BT.601 conversion clips at both ends, which the synthetic video's
+    limited-range content never reaches) and on sizes that exercise the window clamps at the right edge, the chroma-pair
+    selection for odd / even taps and both forms of the row table (duplicate middle row or not): bit-exact against the RGB
+    oracle applied to the converted frames.  1920-wide sources decimate: the two taps of a sample are still adjacent columns."""
+    from oracle import resize_ref as R
+    L, lib = _lib()
+    rs = np.random.RandomState(H * 7 + W)
+    n = g * g + 1
+    nv = rs.randint(0, 256, (n, H * 3 // 2, W)).astype(np.uint8)
+    d = torch.from_numpy(nv).cuda()
+    order = list(rs.permutation(n)[:g * g])
+    idx = torch.tensor(order, dtype=torch.int32, device="cuda")
+    grid = torch.empty((95 * g, 200 * g, 3), dtype=torch.uint8, device="cuda")
+    L.check(lib.tstar_frames_to_grid(d.data_ptr(), n, H, W, idx.data_ptr(), g, g, grid.data_ptr(), 1, None))
+    torch.cuda.synchronize()
+    rgb = [R.nv12_to_rgb(nv[i]) for i in order]
+    assert np.array_equal(grid.cpu().numpy(), R.frames_to_grid(rgb, g, g)), (H, W, g)
+    # the single-step resize on the same frames: 600x285 (4 pixels per lane) and an odd width (1 pixel per lane)
+    m = min(2, len(order))
+    for ow, oh in ((600, 285), (201, 97)):
+        out = torch.empty((m, oh, ow, 3), dtype=torch.uint8, device="cuda")
+        L.check(lib.tstar_frames_resize(d.data_ptr(), n, H, W, idx.data_ptr(), m, ow, oh, out.data_ptr(), 1, None))
+        torch.cuda.synchronize()
+        for k in range(m):
+            assert np.array_equal(out[k].cpu().numpy(), R.cv_bilinear_resize(rgb[k], ow, oh)), (H, W, ow, oh, k)
+
+
 def test_search_on_nv12_store_equals_search_on_converted_rgb_store():
     from tstar_amd.interface_heuristic import OWLInterface
     from tstar_amd.interface_searcher import TStarSearcher

@@ -456,6 +456,212 @@ __global__ __launch_bounds__(256) void frames_to_grid_rgb_kernel(const uint8_t* 
     else { d[0] = (uint8_t)v[0][0]; d[1] = (uint8_t)v[0][1]; d[2] = (uint8_t)v[0][2]; }
 }
 
+// ------------------------------------------------------------------ NV12 fast path of the grid kernel
+// Same structure for NV12 frame stores (luma plane + interleaved half-resolution UV plane).  The generic kernel issues
+// three byte loads per tap (48 per grid pixel); here a (source row, sample) pair is TWO 4-byte windows -- the luma bytes
+// of both taps, and the one or two UV pairs they use -- and every tap is converted with the same BT.601 integer matrix
+// (SrcNV12::at, bit for bit) before it is mixed: (Y, V) / (Y, U) / (U, V) pairs are dropped into 16-bit halves with
+// v_perm_b32 and each channel is one v_dot2_i32_i16 with the constant folded into the accumulator:
+//   R = clip((298 Y + 409 V - 56992) >> 8)    B = clip((298 Y + 516 U - 70688) >> 8)
+//   G = clip((R_pre - 100 U - 617 V + 91776) >> 8)            [= 298 Y - 100 U - 208 V + 34784]
+// X table per output column, three uint4: {oY_A | oC_A << 16, selYU_A.L, selYU_A.R, w_A} {oY_B | oC_B << 16, selYU_B.L,
+// selYU_B.R, w_B} {wFinal, 0, 0, 0}; a selector reads {chroma window, luma window} as bytes 4-7 / 0-3:
+// selYU = lumaByte | 0x0C00 | (4 + uvByte) << 16 | 0x0C000000.  Y table per output row, four uint4: luma row offsets,
+// chroma row offsets (frame-relative bytes), the two pairs of vertical weights << 12, the final pair << 12.
+static void fused_x_sample_nv12(const int4 t, int W, unsigned* off, unsigned* selL, unsigned* selR, unsigned* w) {
+    const int oy = t.x < W - 4 ? t.x : W - 4;                          // 4-byte luma window holding both taps
+    const int cx = t.x & ~1, oc = cx < W - 4 ? cx : W - 4;             // 4-byte chroma window holding both taps' UV pairs
+    const unsigned bL = (unsigned)(t.x - oy), bR = (unsigned)(t.y - oy);
+    const unsigned cL = (unsigned)((t.x & ~1) - oc), cR = (unsigned)((t.y & ~1) - oc);
+    *off = (unsigned)oy | ((unsigned)oc << 16);
+    *selL = bL | 0x0C00u | ((4u + cL) << 16) | 0x0C000000u;
+    *selR = bR | 0x0C00u | ((4u + cR) << 16) | 0x0C000000u;
+    *w = (unsigned)t.z | ((unsigned)t.w << 16);
+}
+
+// kind 4: NV12 X table of the two-step resize (3 uint4 per column); kind 5: NV12 Y table (4 uint4 per row);
+// kind 6 / 7: X / Y table of a single resize src -> dst (1 uint4 per column {oY | oC << 16, selYU.L, selYU.R, w}; 2 uint4
+// per row {luma row 0, luma row 1, chroma row 0, chroma row 1} {b0 << 12, b1 << 12, 0, 0})
+static int get_fused_nv12(int kind, int src, int mid, int dst, int W, int H, const uint4** out) {
+    auto build = [](int s_, int d_, std::vector<int4>& h) {
+        h.resize(d_);
+        const double scale = (double)s_ / d_;
+        for (int d = 0; d < d_; ++d) {
+            float f = (float)((d + 0.5) * scale - 0.5);
+            int s = (int)floorf(f);
+            f -= (float)s;
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s >= s_ - 1) { f = 0.f; s = s_ - 1; }
+            const int s1 = s + 1 < s_ ? s + 1 : s_ - 1;
+            h[d] = make_int4(s, s1, sat_short(cv_round_half_even((1.f - f) * 2048.f)), sat_short(cv_round_half_even(f * 2048.f)));
+        }
+    };
+    std::lock_guard<std::mutex> lk(g_lintab_mu);
+    const auto key = std::make_tuple(kind, src, mid, dst, W * 65536 + H);
+    auto it = g_fused.find(key);
+    if (it == g_fused.end()) {
+        std::vector<int4> h1, h2;
+        std::vector<uint4> h;
+        if (kind == 6 || kind == 7) {
+            build(src, dst, h1);
+            const unsigned hw = (unsigned)H * W;
+            h.resize((kind == 6 ? 1 : 2) * (size_t)dst);
+            for (int d = 0; d < dst; ++d) {
+                if (kind == 6) {
+                    unsigned o, sl, sr, w;
+                    fused_x_sample_nv12(h1[d], W, &o, &sl, &sr, &w);
+                    h[d] = make_uint4(o, sl, sr, w);
+                } else {
+                    h[2 * d] = make_uint4((unsigned)h1[d].x * W, (unsigned)h1[d].y * W, hw + (unsigned)(h1[d].x >> 1) * W, hw + (unsigned)(h1[d].y >> 1) * W);
+                    h[2 * d + 1] = make_uint4((unsigned)h1[d].z << 12, (unsigned)h1[d].w << 12, 0, 0);
+                }
+            }
+        } else {
+            build(src, mid, h1);
+            build(mid, dst, h2);
+        }
+        if (kind == 4) {
+            h.resize(3 * (size_t)dst);
+            for (int d = 0; d < dst; ++d) {
+                unsigned o, sl, sr, w;
+                fused_x_sample_nv12(h1[h2[d].x], W, &o, &sl, &sr, &w);
+                h[3 * d] = make_uint4(o, sl, sr, w);
+                fused_x_sample_nv12(h1[h2[d].y], W, &o, &sl, &sr, &w);
+                h[3 * d + 1] = make_uint4(o, sl, sr, w);
+                h[3 * d + 2] = make_uint4((unsigned)h2[d].z | ((unsigned)h2[d].w << 16), 0, 0, 0);
+            }
+        } else if (kind == 5) {
+            h.resize(4 * (size_t)dst);
+            const unsigned hw = (unsigned)H * W;
+            for (int d = 0; d < dst; ++d) {
+                const int4 a = h1[h2[d].x], b = h1[h2[d].y];
+                h[4 * d] = make_uint4((unsigned)a.x * W, (unsigned)a.y * W, (unsigned)b.x * W, (unsigned)b.y * W);
+                h[4 * d + 1] = make_uint4(hw + (unsigned)(a.x >> 1) * W, hw + (unsigned)(a.y >> 1) * W, hw + (unsigned)(b.x >> 1) * W, hw + (unsigned)(b.y >> 1) * W);
+                h[4 * d + 2] = make_uint4((unsigned)a.z << 12, (unsigned)a.w << 12, (unsigned)b.z << 12, (unsigned)b.w << 12);
+                h[4 * d + 3] = make_uint4((unsigned)h2[d].z << 12, (unsigned)h2[d].w << 12, 0, 0);
+            }
+        }
+        FusedTab t; t.n = (int)h.size();
+        TSTAR_HIP_CHECK(hipMalloc(&t.d, h.size() * sizeof(uint4)));
+        TSTAR_HIP_CHECK(hipMemcpy(t.d, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        it = g_fused.emplace(key, t).first;
+    }
+    *out = it->second.d;
+    return TSTAR_OK;
+}
+
+struct __attribute__((packed)) PackedU32 { unsigned v; };
+__device__ __forceinline__ unsigned load_window32(const uint8_t* p) { return reinterpret_cast<const PackedU32*>(p)->v; }
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sdot2(unsigned pair, unsigned coef, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2_t, pair), __builtin_bit_cast(i16x2_t, coef), acc, false);
+}
+__device__ __forceinline__ unsigned clip_s8(int v) { const int t = v >> 8; return (unsigned)(t < 0 ? 0 : (t > 255 ? 255 : t)); }   // v_med3_i32
+// one tap of an NV12 frame -> RGB (SrcNV12::at), from the luma / chroma windows and the tap's (Y, U) selector
+__device__ __forceinline__ void nv12_tap(unsigned lu, unsigned ch, unsigned sel_yu, unsigned (&rgb)[3]) {
+    const unsigned yu = __builtin_amdgcn_perm(ch, lu, sel_yu);                 // Y | U << 16
+    const unsigned yv = __builtin_amdgcn_perm(ch, lu, sel_yu + 0x00010000u);   // Y | V << 16
+    const unsigned uv = (yu >> 16) | (yv & 0xFFFF0000u);                        // U | V << 16
+    const int rp = sdot2(yv, 298u | (409u << 16), -56992);
+    const int bp = sdot2(yu, 298u | (516u << 16), -70688);
+    const int gp = sdot2(uv, (unsigned)(unsigned short)(-100) | ((unsigned)(unsigned short)(-617) << 16), rp + 91776);
+    rgb[0] = clip_s8(rp); rgb[1] = clip_s8(gp); rgb[2] = clip_s8(bp);
+}
+
+template <bool DUP>
+__device__ __forceinline__ void grid_pixel_nv12(const uint8_t* f, const uint4 yl, const uint4 yc, const uint4 yw, const uint4 yf, const uint4 xa,
+                                                const uint4 xb, const unsigned wfx, unsigned (&v)[3]) {
+    const unsigned lrow[4] = {yl.x, yl.y, yl.z, yl.w}, crow[4] = {yc.x, yc.y, yc.z, yc.w};
+    const unsigned oYa = xa.x & 0xFFFFu, oCa = xa.x >> 16, oYb = xb.x & 0xFFFFu, oCb = xb.x >> 16;
+    const unsigned wa0 = xa.w & 0xFFFFu, wa1 = xa.w >> 16, wb0 = xb.w & 0xFFFFu, wb1 = xb.w >> 16;
+    unsigned ha[4][3], hb[4][3];                                       // horizontal mixes per source row, sample, channel
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (DUP && r == 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ha[2][c] = ha[1][c]; hb[2][c] = hb[1][c]; }
+            continue;
+        }
+        const unsigned la = load_window32(f + (size_t)(lrow[r] + oYa)), ca = load_window32(f + (size_t)(crow[r] + oCa));
+        const unsigned lb = load_window32(f + (size_t)(lrow[r] + oYb)), cb = load_window32(f + (size_t)(crow[r] + oCb));
+        unsigned pl[3], pr[3];
+        nv12_tap(la, ca, xa.y, pl); nv12_tap(la, ca, xa.z, pr);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ha[r][c] = __umul24(pl[c], wa0) + __umul24(pr[c], wa1);
+        nv12_tap(lb, cb, xb.y, pl); nv12_tap(lb, cb, xb.z, pr);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hb[r][c] = __umul24(pl[c], wb0) + __umul24(pr[c], wb1);
+    }
+    const unsigned fxa = wfx & 0xFFFFu, fxb = wfx >> 16;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned p00 = vmix(ha[0][c], ha[1][c], yw.x, yw.y), p01 = vmix(hb[0][c], hb[1][c], yw.x, yw.y);
+        const unsigned p10 = vmix(ha[2][c], ha[3][c], yw.z, yw.w), p11 = vmix(hb[2][c], hb[3][c], yw.z, yw.w);
+        const unsigned h0 = __umul24(p00, fxa) + __umul24(p01, fxb), h1 = __umul24(p10, fxa) + __umul24(p11, fxb);
+        v[c] = vmix(h0, h1, yf.x, yf.y);
+    }
+}
+
+__global__ __launch_bounds__(256) void frames_to_grid_nv12_kernel(const uint8_t* __restrict__ video, size_t frame_bytes, const int* __restrict__ idx,
+                                                                  int cols, int cw, int ch, unsigned magic_cw, const uint4* __restrict__ fx,
+                                                                  const uint4* __restrict__ fy, uint8_t* __restrict__ grid) {
+    const unsigned u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= (unsigned)(cw * ch)) return;
+    const int i = blockIdx.y;
+    const uint8_t* f = video + (size_t)idx[i] * frame_bytes;          // wave-uniform
+    const unsigned oy = __umulhi(u, magic_cw), ox = u - oy * (unsigned)cw;
+    const uint4 xa = fx[3 * ox], xb = fx[3 * ox + 1], xf = fx[3 * ox + 2];
+    unsigned v[3];
+    const unsigned oy_u = __builtin_amdgcn_readfirstlane(oy);
+    if (__all(oy == oy_u)) {                                           // the row entry through the scalar cache (see the RGB kernel)
+        const uint4* q = fy + 4 * oy_u;
+        const uint4 yl = q[0], yc = q[1], yw = q[2], yf = q[3];
+        if (yl.y == yl.z) grid_pixel_nv12<true>(f, yl, yc, yw, yf, xa, xb, xf.x, v);
+        else grid_pixel_nv12<false>(f, yl, yc, yw, yf, xa, xb, xf.x, v);
+    } else {
+        grid_pixel_nv12<false>(f, fy[4 * oy], fy[4 * oy + 1], fy[4 * oy + 2], fy[4 * oy + 3], xa, xb, xf.x, v);
+    }
+    const int gr = i / cols, gc = i - gr * cols;
+    uint8_t* d = grid + (((size_t)gr * ch + oy) * ((size_t)cols * cw) + (size_t)gc * cw + ox) * 3;
+    d[0] = (uint8_t)v[0]; d[1] = (uint8_t)v[1]; d[2] = (uint8_t)v[2];
+}
+
+// NV12 form of the resize kernel: per pixel two rows x (luma window, chroma window), four taps converted, mixed as above
+template <int PX>
+__global__ __launch_bounds__(256) void bilinear_gather_nv12_kernel(const uint8_t* __restrict__ video, size_t frame_bytes, const int* __restrict__ idx,
+                                                                   int ow, int owq, unsigned magic_owq, int nunits, const uint4* __restrict__ fx,
+                                                                   const uint4* __restrict__ fy, uint8_t* __restrict__ out) {
+    const unsigned u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= (unsigned)nunits) return;
+    const int i = blockIdx.y;
+    const uint8_t* f = video + (size_t)idx[i] * frame_bytes;          // wave-uniform
+    const unsigned oy = __umulhi(u, magic_owq), ox = (u - oy * (unsigned)owq) * PX;
+    uint4 yr, yw;
+    const unsigned oy_u = __builtin_amdgcn_readfirstlane(oy);
+    if (__all(oy == oy_u)) { const uint4* q = fy + 2 * oy_u; yr = q[0]; yw = q[1]; }
+    else { yr = fy[2 * oy]; yw = fy[2 * oy + 1]; }
+    unsigned v[PX][3];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const uint4 x = fx[ox + k];
+        const unsigned oY = x.x & 0xFFFFu, oC = x.x >> 16, w0 = x.w & 0xFFFFu, w1 = x.w >> 16;
+        unsigned h[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned lu = load_window32(f + (size_t)((r ? yr.y : yr.x) + oY)), cc = load_window32(f + (size_t)((r ? yr.w : yr.z) + oC));
+            unsigned pl[3], pr[3];
+            nv12_tap(lu, cc, x.y, pl); nv12_tap(lu, cc, x.z, pr);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h[r][c] = __umul24(pl[c], w0) + __umul24(pr[c], w1);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[k][c] = vmix(h[0][c], h[1][c], yw.x, yw.y);
+    }
+    uint8_t* d = out + (((size_t)i * (nunits / owq) + oy) * ow + ox) * 3;
+    if constexpr (PX == 4) store_px4(d, v);
+    else { d[0] = (uint8_t)v[0][0]; d[1] = (uint8_t)v[0][1]; d[2] = (uint8_t)v[0][2]; }
+}
+
 // TSTAR_INGEST_GENERIC=1 forces the generic kernels on RGB sources too (before / after counter runs, tools/pmc_ingest_counters.sh)
 static bool rgb_fast_ok(int W, long long npix, int div) {
     static const bool generic = [] { const char* e = getenv("TSTAR_INGEST_GENERIC"); return e && atoi(e) != 0; }();
@@ -513,6 +719,18 @@ int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int
         const dim3 g((unsigned)((nunits + 255) / 256), (unsigned)n);
         if (px == 4) hipLaunchKernelGGL(bilinear_gather_rgb_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
         else hipLaunchKernelGGL(bilinear_gather_rgb_kernel<1>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
+        TSTAR_HIP_CHECK(hipGetLastError());
+        return TSTAR_OK;
+    }
+    if (nv12 && n <= 65535 && W >= 4 && W <= 65535 && W % 2 == 0 && H % 2 == 0 && rgb_fast_ok(W, (long long)ow * oh, ow) && (size_t)H * W * 3 / 2 < (1ull << 31)) {
+        const uint4 *fx, *fy;
+        rc = get_fused_nv12(6, W, 0, ow, W, H, &fx); if (rc) return rc;
+        rc = get_fused_nv12(7, H, 0, oh, W, H, &fy); if (rc) return rc;
+        const int px = (ow % 4 == 0 && (reinterpret_cast<size_t>(out) & 3) == 0) ? 4 : 1;
+        const int owq = ow / px, nunits = owq * oh;
+        const dim3 g((unsigned)((nunits + 255) / 256), (unsigned)n);
+        if (px == 4) hipLaunchKernelGGL(bilinear_gather_nv12_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3 / 2, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
+        else hipLaunchKernelGGL(bilinear_gather_nv12_kernel<1>, g, dim3(256), 0, s, video, (size_t)H * W * 3 / 2, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
         TSTAR_HIP_CHECK(hipGetLastError());
         return TSTAR_OK;
     }
@@ -574,6 +792,16 @@ int frames_to_grid_u8(const uint8_t* video, int H, int W, const int* d_idx, int 
         const dim3 g((unsigned)((cwq * ch + 255) / 256), (unsigned)(rows * cols));
         if (px == 4) hipLaunchKernelGGL(frames_to_grid_rgb_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, cols, cw, ch, cwq, magic_of(cwq), fx, fy, grid);
         else hipLaunchKernelGGL(frames_to_grid_rgb_kernel<1>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, cols, cw, ch, cwq, magic_of(cwq), fx, fy, grid);
+        TSTAR_HIP_CHECK(hipGetLastError());
+        return TSTAR_OK;
+    }
+    if (nv12 && rows * cols <= 65535 && W >= 4 && W <= 65535 && W % 2 == 0 && H % 2 == 0 && rgb_fast_ok(W, (long long)cw * ch, cw) &&
+        (size_t)H * W * 3 / 2 < (1ull << 31)) {
+        const uint4 *fx, *fy;
+        rc = get_fused_nv12(4, W, 4 * cw, cw, W, H, &fx); if (rc) return rc;
+        rc = get_fused_nv12(5, H, 4 * ch, ch, W, H, &fy); if (rc) return rc;
+        hipLaunchKernelGGL(frames_to_grid_nv12_kernel, dim3((unsigned)((cw * ch + 255) / 256), (unsigned)(rows * cols)), dim3(256), 0, s, video,
+                           (size_t)H * W * 3 / 2, d_idx, cols, cw, ch, magic_of(cw), fx, fy, grid);
         TSTAR_HIP_CHECK(hipGetLastError());
         return TSTAR_OK;
     }
