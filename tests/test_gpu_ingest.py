@@ -244,3 +244,24 @@ def test_y4m_decode_front_end(tmp_path):
     open(shifted, "wb").write(bytes(blob) + bytes(hd2["frame_bytes"]))
     with pytest.raises(ValueError, match="no FRAME marker where frame 4"):
         V.load_y4m(shifted, chunk=16)
+
+
+def test_compressed_webp_video_opens_by_name_and_searches(tmp_path):
+    """A compressed (lossless animated WebP) file path handed to TStarSearcher like the reference hands an .mp4 to decord:
+    decoded once by the Pillow front end into the resident store, then the ordinary device path."""
+    from PIL import Image
+    from tstar_amd import video as V
+    from tstar_amd.interface_searcher import TStarSearcher
+    import golden_util as GU
+    frames = V.synthetic_frames_numpy(list(range(40)), 40, 72, 128, seed=4)
+    pil = [Image.fromarray(f) for f in frames]
+    path = str(tmp_path / "clip.webp")
+    pil[0].save(path, save_all=True, append_images=pil[1:], duration=500, loop=0, lossless=True)      # 2 fps -> 20 logical seconds
+    st = V.open_video(path)
+    assert st.fmt == "rgb" and st.num_seconds == 20 and st.raw_fps == 2.0 and st.frames.is_cuda
+    assert np.array_equal(st.frames.cpu().numpy(), frames[::2])
+    s = TStarSearcher(video_path=path, heuristic=GU.FakeHeuristic(0), target_objects=["a"], cue_objects=[], search_nframes=4,
+                      image_grid_shape=(2, 2), search_budget=0.5, confidence_threshold=0.5, rng=np.random.RandomState(1))
+    out, ts = s.search()
+    assert out.shape == (4, 72, 128, 3) and s.total_frame_num == 20 and s.raw_fps == 2.0
+    assert all(np.array_equal(out[k], frames[int(t * 2.0)]) for k, t in enumerate(ts))

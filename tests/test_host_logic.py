@@ -415,3 +415,36 @@ def test_real_checkpoint_directory_host_side(tmp_path):
     # a different directory without vocabulary files does not inherit this one's tokenizer (per-path cache)
     with pytest.raises(RuntimeError, match="no CLIP tokenizer files"):
         encode_queries([["couch"]], str(tmp_path / "nowhere"), allow_standin=False)
+
+
+def test_compressed_sequence_front_end(tmp_path):
+    """SURVEY.md 8f-3 with what this image can decode: animated WebP (VP8L), GIF (LZW), APNG and AVIF sequences (AV1) through
+    Pillow -- the only compressed multi-frame decoders present (no FFmpeg / rocDecode / decord / cv2).  The store holds raw
+    frame int(sec * fps) for every logical second (interface_searcher.py:360); the rate comes from the frame durations,
+    also when they vary (second decode pass at the true rate).  Lossless containers must reproduce the frames exactly."""
+    from PIL import Image
+    from tstar_amd import video as V
+    rs = np.random.RandomState(0)
+    frames = [np.kron(rs.randint(0, 256, (9, 16, 3)), np.ones((4, 4, 1))).astype(np.uint8) for _ in range(14)]
+    pil = [Image.fromarray(f) for f in frames]
+    for ext, kw, exact in ((".webp", dict(lossless=True), True), (".gif", {}, True), (".png", {}, True), (".avif", dict(quality=100, subsampling="4:4:4"), False)):
+        p = str(tmp_path / ("clip" + ext))
+        pil[0].save(p, save_all=True, append_images=pil[1:], duration=250, loop=0, **kw)
+        st = V.open_video(p, device="cpu")
+        assert st.raw_fps == 4.0 and st.raw_total_frames == 14 and st.num_seconds == 3 and st.shape == (3, 36, 64, 3), ext
+        got = st.frames.numpy()
+        for sec in range(3):
+            err = np.abs(got[sec].astype(np.int32) - frames[4 * sec].astype(np.int32))
+            assert (err.max() == 0) if exact else (err.max() <= 6 and err.mean() < 2.0), (ext, sec, err.max(), err.mean())      # AV1 is lossy even at q = 100
+    # varying durations: 8 frames of 125 ms then 6 of 500 ms = 4 s -> 3.5 fps, seconds 0..3 are raw frames 0, 3, 7, 10
+    p = str(tmp_path / "vary.webp")
+    pil[0].save(p, save_all=True, append_images=pil[1:], duration=[125] * 8 + [500] * 6, loop=0, lossless=True)
+    st = V.open_video(p, device="cpu")
+    assert st.raw_fps == 3.5 and st.num_seconds == 4
+    assert all(np.array_equal(st.frames.numpy()[s], frames[int(s * 3.5)]) for s in range(4))
+    # a single still image is not a video; a missing file reads like the reference's error
+    pil[0].save(str(tmp_path / "still.png"))
+    with pytest.raises(ValueError, match="Cannot open video file"):
+        V.open_video(str(tmp_path / "still.png"), device="cpu")
+    with pytest.raises(ValueError, match="Cannot open video file"):
+        V.open_video(str(tmp_path / "missing.webp"), device="cpu")

@@ -6,9 +6,10 @@ frame count (:60-65).  Here a video is decoded ONCE into a uint8 tensor
 [N,H,W,3] (RGB) on the GPU and every later gather/resize is a HIP kernel
 (tstar_frames_to_grid / tstar_frames_resize).  Decode itself (FFmpeg/VCN) is
 outside the hot path (SURVEY.md 8f "next" row 3): raw 4:2:0 files (YUV4MPEG2) are
-read and repacked on the device here (``load_y4m``); compressed files need decord
-or cv2 on the host (rocDecode / FFmpeg are not in this build), synthetic videos
-need nothing.
+read and repacked on the device here (``load_y4m``); the compressed sequences Pillow
+decodes in this image (animated GIF / WebP, AVIF sequences = AV1) go through
+``load_pillow_sequence``; other compressed files need decord or cv2 on the host
+(rocDecode / FFmpeg are not in this build), synthetic videos need nothing.
 """
 from __future__ import annotations
 
@@ -269,6 +270,65 @@ def write_y4m(path: str, nv12_frames: np.ndarray, fps=(1, 1)) -> None:
             f.write(np.ascontiguousarray(uv[..., 1]).tobytes())
 
 
+_PIL_SEQUENCE_EXT = (".gif", ".webp", ".avif", ".avifs", ".apng", ".png")
+
+
+def load_pillow_sequence(path: str, device: str = "cuda", chunk: int = 64) -> FrameStore:
+    """Decode front end for the compressed multi-frame containers Pillow reads in this image -- animated GIF (LZW), WebP
+    (VP8 / VP8L) and AVIF image sequences (AV1 through libavif) -- the only compressed "video" decoders available here
+    (no FFmpeg, rocDecode, decord or cv2).  The stream's rate comes from the frame durations (frames / total duration);
+    the frames the searcher can ever ask for (raw frame int(sec * fps) for every logical second,
+    interface_searcher.py:360) are decoded once on the host, converted to RGB and copied to HBM in chunks -- the role
+    decord's CPU reader plays in the reference (:157-169), without the reopen per call."""
+    import torch
+    from PIL import Image
+    try:
+        im = Image.open(path)
+    except Exception as e:
+        raise ValueError(f"Cannot open video file: {path} ({e})")
+    with im:
+        n = int(getattr(im, "n_frames", 1))
+        w, h = im.size
+
+        def frame(i):
+            """RGB frame i and its duration in ms (WebP / AVIF report the duration only once the frame is decoded)."""
+            im.seek(i)
+            im.load()
+            return np.asarray(im.convert("RGB"), dtype=np.uint8), float(im.info.get("duration", 0) or 0)
+
+        def wanted(fps):
+            n_sec = int(n / fps)
+            return n_sec, {int(sec * fps): sec for sec in range(n_sec)}
+
+        # One decode pass under the hypothesis that every frame lasts as long as the first (the usual case); the pass also
+        # collects the real durations, and only a stream with varying durations is decoded a second time at its true rate.
+        f0, d0 = frame(0)
+        if n < 1 or d0 <= 0:
+            raise ValueError(f"Cannot open video file: {path} (no frame durations: not an animated sequence)")
+        fps = 1000.0 / d0
+        for attempt in range(2):
+            n_sec, want = wanted(fps)
+            if n_sec < 1:
+                raise ValueError(f"Cannot open video file: {path} (shorter than one second)")
+            store = torch.empty((n_sec, h, w, 3), dtype=torch.uint8, device=device)
+            host = np.empty((min(chunk, n_sec), h, w, 3), dtype=np.uint8)
+            total_ms, filled, base = 0.0, 0, 0
+            for i in range(n):
+                fr, d = (f0, d0) if i == 0 else frame(i)
+                total_ms += d
+                if i in want:                               # raw indices grow with the second, so seconds arrive in order
+                    host[filled] = fr
+                    filled += 1
+                    if filled == len(host) or want[i] == n_sec - 1:
+                        store[base:base + filled].copy_(torch.from_numpy(host[:filled]))
+                        base, filled = base + filled, 0
+            true_fps = n * 1000.0 / total_ms
+            if abs(true_fps - fps) <= 1e-9 * fps:
+                break
+            fps = true_fps                                  # varying durations: decode again at the stream's real rate
+    return FrameStore(store, fps, n, name=path)
+
+
 _SYN = re.compile(r"^synthetic://")
 
 
@@ -291,6 +351,11 @@ def open_video(video, device: str = "cuda") -> FrameStore:
         if not os.path.isfile(video):
             raise ValueError(f"Cannot open video file: {video}")
         return load_y4m(video, device)
+    if isinstance(video, str) and video.lower().endswith(_PIL_SEQUENCE_EXT):
+        import os
+        if not os.path.isfile(video):
+            raise ValueError(f"Cannot open video file: {video}")
+        return load_pillow_sequence(video, device)
     try:
         from decord import VideoReader, cpu  # type: ignore
         vr = VideoReader(video, ctx=cpu(0))
