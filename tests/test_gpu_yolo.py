@@ -102,7 +102,7 @@ def test_other_model_scales(scale):
     det.close()
 
 
-@pytest.mark.parametrize("scale,batch", [("s", 3), ("m", 2), ("s", 5)])
+@pytest.mark.parametrize("scale,batch", [("s", 3), ("m", 2)])
 def test_conv_kernels_bit_identical(scale, batch):
     """The VALU convolution kernels (LDS-tiled with 128- / 64-pixel tiles, scalar-weight with 8 / 4 pixels per lane, and its
     halo-tile forms for 3x3 layers: 8 x 40 patches on the 160- / 80- / 40-wide maps, 16 x 20 patches over the row-stacked
