@@ -57,8 +57,8 @@ def parse():
                     help="YOLO-World backend: detector images per forward chunk.  Sized for the chip, not a power of two: the halo conv "
                          "kernel holds 3 workgroups per CU (768 slots) and a 40x40 / 256-channel layer is 20 B workgroups, an 80x80 / 128 "
                          "layer 40 B, a 160x160 / 64 layer 80 B -- B = 38 fills exactly 1 / 2 / 4 rounds, 76 twice that (B = 32 leaves a "
-                         "sixth of the slots idle: 84.7 vs 91.8 / 98.3 TFLOP/s per forward, tools/yolo_batch_sweep.py); with 16 searches "
-                         "in lock-step an iteration verifies about 150 frames = two chunks of 76 (+ a small remainder)")
+                         "sixth of the slots idle: 84.7 vs 91.8 / 98.3 TFLOP/s per forward, tools/yolo_batch_sweep.py); with 24 searches "
+                         "in lock-step an iteration verifies about 228 frames = three chunks of 76 (+ a small remainder)")
     ap.add_argument("--nframes", type=int, default=N_FRAMES)
     ap.add_argument("--search-nframes", type=int, default=8)
     ap.add_argument("--weights", choices=["f32", "bf16", "bf16_exact", "f32_split"], default="f32",
@@ -73,8 +73,9 @@ def parse():
     ap.add_argument("--lockstep", type=int, default=0,
                     help="independent (video, question) items advanced in lock-step per detector batch "
                          "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time; default 4 "
-                         "with the OWL-ViT backend, 16 with YOLO-World (its grid forwards run at B = the group size: 57 TFLOP/s at 8, "
-                         "72 at 16, and an iteration's ~150 verification frames fill two full chunks)")
+                         "with the OWL-ViT backend, 24 with YOLO-World (its grid forwards run at B = the group size: 57 TFLOP/s at 8, "
+                         "72 at 16, 84 at 24, and an iteration's ~228 verification frames fill three full chunks of 76: 12.3 k frames/s "
+                         "against 12.05 k at 16 and 12.15 k at 31 in a same-box A/B; run it with --steps 48)")
     ap.add_argument("--heuristic", choices=["owl", "yolo"], default="owl",
                     help="detector backend: owl = OWL-ViT-B/32 (configs[1], the headline); yolo = YOLO-World-v2-L on the f32 VALU, no "
                          "MFMA (BASELINE configs[3]; parity of that model is unpinned: its source is not in the reference tree)")
@@ -97,7 +98,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
     if args.lockstep <= 0:
-        args.lockstep = 16 if args.heuristic == "yolo" else 4
+        args.lockstep = 24 if args.heuristic == "yolo" else 4
     return args
 
 
@@ -465,8 +466,8 @@ def main():
     if world > 1:                      # create the library's RCCL communicator before the timer (a one-off, like NCCL init)
         gather_keyframes([[0]], world)
     barrier()
-    # time every 5th GEMM / attention launch with HIP event pairs (5 is co-prime with the 4-GEMM layer
-    # pattern and the 52-GEMM forward, so every shape is sampled evenly); timing all of them costs 2.2 %
+    # time one GEMM / attention / conv launch out of every 5 consecutive ones with HIP event pairs, at a position that
+    # changes from block to block (csrc/prof.hip: no aliasing with the launch pattern); timing all of them costs 2.2 %
     _lib.check(lib.tstar_prof_enable(0 if os.environ.get('TSTAR_BENCH_NO_PROF') else PROF_STRIDE))
 
     def stamp(which):

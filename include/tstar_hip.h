@@ -306,8 +306,8 @@ int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int head
 int tstar_attention_split(const float* d_qkv, float* d_out, int B, int T, int heads, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream, for bench.py's roofline leg.
- * category 0 = gemm_f32_kernel, 1 = attention_f32_kernel, 2 = conv_valu_kernel (YOLO-World backend).  enable(n > 0) resets the counters and times every
- * n-th launch of each category (n = 1: all; a stride co-prime with the 4-GEMM layer pattern samples all shapes);
+ * category 0 = gemm_f32_kernel, 1 = attention_f32_kernel, 2 = conv_valu_kernel (YOLO-World backend).  enable(n > 0) resets the counters and times ONE of every
+ * n consecutive launches of each category, at a position that varies from block to block (n = 1: all; a fixed phase would alias with periodic launch patterns);
  * read() synchronises the recorded events and returns launches / total ms / total algorithmic flops. */
 int tstar_prof_enable(int on);
 int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops);
