@@ -363,7 +363,25 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL over xGMI.  Should the communicator not come up on this node (driver / IPC configuration), the job still
+            # measures: the ranks fall back to gloo for the barriers and the one gather (host tensors), and say so in the
+            # line (config.collective_backend / collective_path) -- the data path has no collective either way.
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce probe returned {probe.item()} instead of {world}")
+            except Exception as e:                      # every rank sees the same failure of a collective bring-up
+                print(f"bench.py[rank {rank}]: RCCL bring-up failed ({e!r}); falling back to gloo", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)      # a fresh store
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
     cdev = "cuda" if backend == "nccl" else "cpu"
