@@ -96,6 +96,11 @@ int tstar_owl_destroy(tstar_owl* h);
  * Synchronises `stream`. */
 int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_input_ids, const int32_t* h_attention_mask,
                           const double* h_class_weight, int Q, void* stream);
+/* Several query sets in ONE text-tower forward (a lock-step group installs the questions of all its items at once): h_sets
+ * [n_sets] slots, h_Q [n_sets] queries per set, ids / attention masks [sum Q][16] and class weights [sum Q] concatenated in
+ * set order.  Same kernels as tstar_owl_set_queries on more rows; results are bit-identical to one call per set.  Synchronises. */
+int tstar_owl_set_queries_many(tstar_owl* h, int n_sets, const int32_t* h_sets, const int32_t* h_Q, const int32_t* h_ids,
+                               const int32_t* h_am, const double* h_w, void* stream);
 /* Same, from precomputed L2-normalised embeddings float32 [Q,512] and query mask u8 [Q]. */
 int tstar_owl_set_query_embeds(tstar_owl* h, int query_set, const float* h_query_embeds, const uint8_t* h_query_mask,
                                const double* h_class_weight, int Q, void* stream);

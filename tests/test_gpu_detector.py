@@ -248,3 +248,35 @@ def test_score_requires_queries():
         s.score(torch.zeros((1, 95, 200, 3), dtype=torch.uint8, device="cuda"), 1, 1)
     with pytest.raises(_lib.TStarHipError, match="without text weights"):
         s.set_queries(np.zeros((1, 16), np.int32), np.ones((1, 16), np.int32), [1.0])
+
+
+def test_install_queries_many_equals_one_by_one():
+    """A lock-step group installs the questions of all its items through ONE text-tower forward
+    (tstar_owl_set_queries_many): query embeddings, masks and class weights must equal one install per item bit for bit --
+    also when the text-only handle of the YOLO-World backend (40 sequences per forward) has to cut the group into several
+    forwards -- and an image scored against a slot gives the same scores either way."""
+    import golden_util as GU
+    from tstar_amd.interface_heuristic import OWLInterface, YoloWorldInterface
+    questions = [(["couch"], ["tv", "chair"]), (["dog"], ["leash", "park bench"]), (["red car"], ["road"]), (["laptop", "mug"], ["desk"]),
+                 (["a"], []), (["person riding a horse on the beach"], ["sand", "sea", "sky", "sun"])]
+    h = OWLInterface(synthetic_seed=0, max_batch=2)
+    items = [(k + 1, list(t), list(c), {t[0]: 0.75}) for k, (t, c) in enumerate(questions)]
+    texts_many = h.install_queries_many(items)
+    many = [(h.scorer.get_query_embeds(slot).copy(), h.scorer.Qs[slot]) for slot, *_ in items]
+    img = torch.from_numpy(GU.detector_test_image(5, 285, 600)).cuda().unsqueeze(0)
+    r_many = [h.score_batch(img, 1, 1, image_sets=[slot]).scores.clone() for slot, *_ in items]
+    for (slot, t, c, o2w), tm, (e_many, q_many), sc in zip(items, texts_many, many, r_many):
+        tx = h.install_queries(slot, t, c, o2w)
+        assert tx == tm and h.scorer.Qs[slot] == q_many
+        assert np.array_equal(h.scorer.get_query_embeds(slot), e_many), slot
+        assert torch.equal(h.score_batch(img, 1, 1, image_sets=[slot]).scores, sc), slot
+    with pytest.raises(ValueError, match="slot must be in 1..31"):
+        h.install_queries_many([(0, ["a"], [], None)])
+    # text-only handle: 12 items x 5 queries = 60 sequences > 40 per forward
+    y = YoloWorldInterface(synthetic_seed=0, scale="s", max_batch=1)
+    yitems = [(k + 1, [f"thing {k}"], ["one", "two three", "four"], None) for k in range(12)]
+    y.install_queries_many(yitems)
+    feats = [y.text_tower.get_query_embeds(slot).copy() for slot, *_ in yitems]
+    for (slot, t, c, o2w), f in zip(yitems, feats):
+        y.install_queries(slot, t, c, o2w)
+        assert np.array_equal(y.text_tower.get_query_embeds(0), f), slot          # install_queries encodes through text slot 0

@@ -28,6 +28,7 @@ SIGNATURES = {
     "tstar_owl_create": (_i, [C.POINTER(_vp), _vp, _sz, _vp, _sz, _vp, _i, _i]),
     "tstar_owl_destroy": (_i, [_vp]),
     "tstar_owl_set_queries": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "tstar_owl_set_queries_many": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tstar_owl_set_query_embeds": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
     "tstar_owl_set_class_weights": (_i, [_vp, _i, _vp, _i, _vp]),
     "tstar_owl_get_query_embeds": (_i, [_vp, _i, _vp, _i, _vp]),

@@ -99,6 +99,7 @@ struct tstar_owl {
     int image_set_cap = 0;
     int *d_ids = nullptr, *d_eos = nullptr;
     uint8_t* d_kmask = nullptr;
+    int seq_cap = TSTAR_OWL_MAX_QUERIES;                             // sequences the three staging buffers above hold
     std::map<int, ResampleTable> tabs;   // in_size -> table to 768
     // weights_mode 1 / 3 (BASELINE config 5, bf16 weights; two-term / exact three-term activations): bfloat16 copy of every
     // GEMM weight matrix; weights_mode 2 (f32 split): two bfloat16 terms hi + lo per matrix (16 significand bits)
@@ -371,6 +372,83 @@ int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_ids, con
                        h->q_raw + (size_t)query_set * TSTAR_OWL_MAX_QUERIES * PROJ, 0.0f);
     TSTAR_HIP_CHECK(hipGetLastError());
     return finish_queries(h, query_set, qm.data(), h_w, Q, s);
+}
+
+int tstar_owl_set_queries_many(tstar_owl* h, int n_sets, const int32_t* h_sets, const int32_t* h_Q, const int32_t* h_ids, const int32_t* h_am,
+                               const double* h_w, void* stream) {
+    TSTAR_REQUIRE(h && h_sets && h_Q && h_ids && h_am && h_w, "tstar_owl_set_queries_many: null argument");
+    TSTAR_REQUIRE(n_sets >= 1 && n_sets <= TSTAR_OWL_MAX_SETS, "tstar_owl_set_queries_many: n_sets must be in 1..32");
+    if (!h->has_text) { set_error("tstar_owl_set_queries_many: handle was created without text weights"); return TSTAR_ERR_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    int total = 0;
+    for (int i = 0; i < n_sets; ++i) {
+        CHECK_SET(h_sets[i], "tstar_owl_set_queries_many");
+        TSTAR_REQUIRE(h_Q[i] >= 1 && h_Q[i] <= TSTAR_OWL_MAX_QUERIES, "tstar_owl_set_queries_many: every Q must be in 1..32");
+        total += h_Q[i];
+    }
+    for (int q = 0; q < total * T_LEN; ++q) TSTAR_REQUIRE(h_ids[q] >= 0 && h_ids[q] < T_VOCAB, "tstar_owl_set_queries_many: token id out of range");
+    // sequences per text forward: what the activation workspace holds (mpad rows of >= T_D floats; T_LEN rows per sequence)
+    const int cap = (int)(h->mpad / T_LEN);
+    TSTAR_REQUIRE(cap >= TSTAR_OWL_MAX_QUERIES, "tstar_owl_set_queries_many: workspace too small");
+    if (h->seq_cap < cap) {                                   // staging for ids / EOS positions / key masks of one forward
+        TSTAR_HIP_CHECK(hipStreamSynchronize(s));
+        if (h->d_ids) (void)hipFree(h->d_ids);
+        if (h->d_eos) (void)hipFree(h->d_eos);
+        if (h->d_kmask) (void)hipFree(h->d_kmask);
+        h->d_ids = nullptr; h->d_eos = nullptr; h->d_kmask = nullptr; h->seq_cap = 0;
+        TSTAR_HIP_CHECK(hipMalloc(&h->d_ids, (size_t)cap * T_LEN * sizeof(int)));
+        TSTAR_HIP_CHECK(hipMalloc(&h->d_eos, (size_t)cap * sizeof(int)));
+        TSTAR_HIP_CHECK(hipMalloc(&h->d_kmask, (size_t)cap * T_LEN));
+        h->seq_cap = cap;
+    }
+    std::vector<int> eos(total);
+    std::vector<uint8_t> km((size_t)total * T_LEN), qm(total);
+    for (int q = 0; q < total; ++q) {
+        int best = 0;
+        for (int t = 0; t < T_LEN; ++t) {
+            if (h_ids[q * T_LEN + t] > h_ids[q * T_LEN + best]) best = t;   // argmax, first occurrence
+            km[(size_t)q * T_LEN + t] = h_am[q * T_LEN + t] != 0;
+        }
+        eos[q] = best;
+        qm[q] = h_ids[q * T_LEN] > 0;
+    }
+    // ONE text forward per group of sets that fits the workspace: the same kernels as tstar_owl_set_queries on more rows (every
+    // GEMM tile shape and the per-sequence causal attention give the same bits whatever the batch: results equal one-by-one calls)
+    int i0 = 0, q0 = 0;
+    while (i0 < n_sets) {
+        int i1 = i0, nseq = 0;
+        while (i1 < n_sets && nseq + h_Q[i1] <= cap) nseq += h_Q[i1++];
+        const int M = nseq * T_LEN;
+        TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_ids, h_ids + (size_t)q0 * T_LEN, (size_t)M * sizeof(int), hipMemcpyHostToDevice, s));
+        TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_eos, eos.data() + q0, nseq * sizeof(int), hipMemcpyHostToDevice, s));
+        TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_kmask, km.data() + (size_t)q0 * T_LEN, M, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(128), 0, s, h->d_ids, h->tw.tok_emb, h->tw.tpos_emb, h->x, T_LEN, T_D);
+        TSTAR_HIP_CHECK(hipGetLastError());
+        RC(run_encoder(h, h->tw.layers, T_LAYERS, nseq, T_LEN, T_D, T_FF, T_HEADS, 1, h->d_kmask, s));
+        RC(layernorm_f32(h->x, h->xn, h->tw.final_ln_w, h->tw.final_ln_b, M, T_D, s));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(nseq), dim3(128), 0, s, h->xn, h->d_eos, h->att, T_LEN, T_D);
+        TSTAR_HIP_CHECK(hipGetLastError());
+        RC(gemm_f32(mk_gemm(h, h->att, h->tw.text_proj, h->hid, nullptr, nullptr, nseq, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
+        int off = 0;
+        for (int i = i0; i < i1; ++i) {
+            const int set = h_sets[i], Q = h_Q[i];
+            const size_t qo = (size_t)set * TSTAR_OWL_MAX_QUERIES;
+            hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->hid + (size_t)off * PROJ, h->q_raw + qo * PROJ, 0.0f);
+            hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->q_raw + qo * PROJ, h->qn + qo * PROJ, 1e-6f);
+            TSTAR_HIP_CHECK(hipGetLastError());
+            TSTAR_HIP_CHECK(hipMemcpyAsync(h->qmask + qo, qm.data() + q0 + off, Q, hipMemcpyHostToDevice, s));
+            TSTAR_HIP_CHECK(hipMemcpyAsync(h->qweight + qo, h_w + q0 + off, Q * sizeof(double), hipMemcpyHostToDevice, s));
+            h->Q[set] = Q;
+            off += Q;
+        }
+        // the staging buffers are reused by the next group: wait for this one
+        TSTAR_HIP_CHECK(hipStreamSynchronize(s));
+        q0 += nseq;
+        i0 = i1;
+    }
+    TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_setQ, h->Q, sizeof(h->Q), hipMemcpyHostToDevice, s));
+    TSTAR_HIP_CHECK(hipStreamSynchronize(s));
+    return TSTAR_OK;
 }
 
 int tstar_owl_set_query_embeds(tstar_owl* h, int query_set, const float* h_qe, const uint8_t* h_mask, const double* h_w,

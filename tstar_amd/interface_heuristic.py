@@ -180,6 +180,26 @@ class OWLInterface(HeuristicInterface):
         self.scorer.set_queries(ids, am, [float(o2w.get(t[0], 0.5)) for t in texts], slot=int(slot))
         return texts
 
+    def _query_entry(self, slot, target_objects, cue_objects, object2weight):
+        if not 1 <= int(slot) <= 31:
+            raise ValueError("install_queries: slot must be in 1..31")
+        texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
+        ids, am = encode_queries(texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
+        o2w = dict(object2weight or {})
+        for o in target_objects:
+            o2w.setdefault(o, 1.0)
+        for o in cue_objects:
+            o2w.setdefault(o, 0.5)
+        return texts, (int(slot), ids, am, [float(o2w.get(t[0], 0.5)) for t in texts])
+
+    def install_queries_many(self, items) -> List[List[List[str]]]:
+        """``install_queries`` for several slots at once -- ``items``: [(slot, target_objects, cue_objects, object2weight)] -- with
+        the text tower run ONCE over all their queries (a lock-step group installs the questions of its items together).
+        Returns the texts list of every slot; identical to one ``install_queries`` call per item."""
+        built = [self._query_entry(*it) for it in items]
+        self.scorer.set_queries_many([e for _, e in built])
+        return [t for t, _ in built]
+
     def annotated_batch(self, d_images, r, start: int = 0, count: Optional[int] = None):
         """Device form of ``bbox_visualization`` + ``Detections`` for images that are already on the device (the
         searcher's visual history): paints the kept boxes of ``r`` (images ``start .. start+count`` of a
@@ -348,6 +368,29 @@ class YoloWorldInterface(HeuristicInterface):
             o2w.setdefault(o, 0.5)
         self._encode(texts, [float(o2w.get(t[0], 0.5)) for t in texts], int(slot))
         return texts
+
+    def install_queries_many(self, items) -> List[List[List[str]]]:
+        """``install_queries`` for several slots with ONE run of the CLIP text tower over all their queries (the text tower keeps
+        the same slot numbers; each slot's normalised text features then go to the detector's guide layers)."""
+        out, entries, weights = [], [], []
+        for slot, target_objects, cue_objects, object2weight in items:
+            if not 1 <= int(slot) <= 31:
+                raise ValueError("install_queries: slot must be in 1..31")
+            texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
+            o2w = dict(object2weight or {})
+            for o in target_objects:
+                o2w.setdefault(o, 1.0)
+            for o in cue_objects:
+                o2w.setdefault(o, 0.5)
+            w = [float(o2w.get(t[0], 0.5)) for t in texts]
+            ids, am = encode_queries(texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
+            entries.append((int(slot), ids, am, w))
+            weights.append(w)
+            out.append(texts)
+        self.text_tower.set_queries_many(entries)
+        for (slot, _, _, _), w in zip(entries, weights):
+            self.detector.set_text_feats(self.text_tower.get_query_embeds(slot), w, slot=slot)
+        return out
 
     def annotated_batch(self, d_images, r, start: int = 0, count: Optional[int] = None):
         """Images + detections of a ``score_batch`` result on the host, boxes painted (<= 50 per image: host painter)."""

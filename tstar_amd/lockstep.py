@@ -45,7 +45,13 @@ def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray
     n = rows * cols
     for i, s in enumerate(searchers):
         s._slot = i + 1
-        s._texts = h.install_queries(s._slot, s.target_objects, s.cue_objects, s.object2weight)
+    if hasattr(h, "install_queries_many"):                   # one text-tower forward for the whole group's questions
+        texts = h.install_queries_many([(s._slot, s.target_objects, s.cue_objects, s.object2weight) for s in searchers])
+        for s, t in zip(searchers, texts):
+            s._texts = t
+    else:
+        for s in searchers:
+            s._texts = h.install_queries(s._slot, s.target_objects, s.cue_objects, s.object2weight)
 
     def active():
         return [s for s in searchers if s.remaining_targets and s.search_budget > 0]

@@ -118,6 +118,26 @@ class OwlScorer:
         _lib.check(rc, "tstar_owl_set_queries")
         self.Qs[int(slot)] = Q
 
+    def set_queries_many(self, entries):
+        """``entries``: [(slot, input_ids [Q,16], attention_mask [Q,16], class_weight [Q])] -- the queries of several slots through
+        ONE text-tower forward (tstar_owl_set_queries_many); bit-identical to one ``set_queries`` call per slot."""
+        if not entries:
+            return
+        slots = np.ascontiguousarray([int(e[0]) for e in entries], dtype=np.int32)
+        ids = [np.ascontiguousarray(e[1], dtype=np.int32) for e in entries]
+        am = [np.ascontiguousarray(e[2], dtype=np.int32) for e in entries]
+        w = [np.ascontiguousarray(e[3], dtype=np.float64) for e in entries]
+        for i_, a_, w_ in zip(ids, am, w):
+            if i_.ndim != 2 or i_.shape[1] != W.T_LEN or a_.shape != i_.shape or w_.shape != (i_.shape[0],):
+                raise ValueError("set_queries_many: ids/mask must be [Q,16] and class_weight [Q] per entry")
+        Qs = np.ascontiguousarray([i_.shape[0] for i_ in ids], dtype=np.int32)
+        ids_c, am_c, w_c = np.concatenate(ids), np.concatenate(am), np.concatenate(w)
+        rc = self._lib.tstar_owl_set_queries_many(self._h, len(entries), slots.ctypes.data, Qs.ctypes.data, ids_c.ctypes.data, am_c.ctypes.data,
+                                                  w_c.ctypes.data, _lib.stream_ptr())
+        _lib.check(rc, "tstar_owl_set_queries_many")
+        for sl, q in zip(slots, Qs):
+            self.Qs[int(sl)] = int(q)
+
     def set_query_embeds(self, embeds: np.ndarray, query_mask: Sequence[int], class_weight: Sequence[float], slot: int = 0):
         e = np.ascontiguousarray(embeds, dtype=np.float32)
         m = np.ascontiguousarray(query_mask, dtype=np.uint8)
