@@ -124,7 +124,9 @@ class OWLInterface(HeuristicInterface):
         # default weights = the searcher's own defaults (target 1.0, cue 0.5, unknown 0.5;
         # interface_searcher.py:88-91,136); a searcher overrides them via set_class_weights
         w = [1.0] * len(target_objects) + [0.5] * len(cue_objects) + [0.5]
-        self.scorer.set_queries(ids, am, w)
+        # recorded now, run through the text tower when slot 0 is first used (OwlScorer.set_queries): a searcher's constructor
+        # calls this like the reference's, but a lock-step group never scores against slot 0
+        self.scorer.set_queries(ids, am, w, lazy=True)
         self._class_weight = np.asarray(w, dtype=np.float64)
 
     def inference_detector(self, images, **kwargs) -> List[Detections]:
@@ -294,6 +296,7 @@ class YoloWorldInterface(HeuristicInterface):
         self.texts = []
         self.detections_inbatch: List[Detections] = []
         self._text_feats = None
+        self._pending0 = None
         self.set_BBoxAnnotator()
 
     def set_BBoxAnnotator(self):
@@ -314,8 +317,20 @@ class YoloWorldInterface(HeuristicInterface):
         combined = list(target_objects) + list(cue_objects)
         self.texts = [[obj.strip()] for obj in combined] + [[' ']]
         w = [1.0] * len(target_objects) + [0.5] * len(cue_objects) + [0.5]
-        self._text_feats = self._encode(self.texts, w, 0)
+        # tokenised now (a missing vocabulary must be reported here), run through the CLIP text tower when slot 0 is first used
+        ids, am = encode_queries(self.texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
+        self._pending0 = (ids, am, list(w))
+        self._text_feats = None
         self._class_weight = np.asarray(w, dtype=np.float64)
+
+    def _flush0(self):
+        """Install the recorded queries of slot 0 (see ``reparameterize_object_list``)."""
+        p = getattr(self, "_pending0", None)
+        if p is not None:
+            self._pending0 = None
+            self.text_tower.set_queries(p[0], p[1], p[2], slot=0)
+            self._text_feats = self.text_tower.get_query_embeds(0)
+            self.detector.set_text_feats(self._text_feats, p[2], slot=0)
 
     def inference_detector(self, images, max_dets: int = 50, score_threshold: float = 0.12, use_amp: bool = False) -> List[Detections]:
         """(:136-168) only ``images[0]``; detections with score > ``score_threshold``, the ``max_dets`` best, descending."""
@@ -323,6 +338,7 @@ class YoloWorldInterface(HeuristicInterface):
         img = np.array(images[0], dtype=np.uint8, order="C")
         if img.ndim != 3 or img.shape[2] != 3:
             raise ValueError("inference_detector expects HxWx3 uint8 RGB images")
+        self._flush0()
         r = self.detector.detect(torch.from_numpy(img).cuda().unsqueeze(0), 1, 1, score_threshold=score_threshold, max_dets=max_dets,
                                  want_cells=False)
         dets = [self._detections_from(r, 0)]
@@ -350,10 +366,15 @@ class YoloWorldInterface(HeuristicInterface):
     # ---- fast-path extensions (same contract as OWLInterface) -----------------------------
     def set_class_weights(self, object2weight: Dict[str, float]):
         w = [float(object2weight.get(t[0], 0.5)) for t in self.texts]
-        self.detector.set_class_weights(w)
+        if getattr(self, "_pending0", None) is not None:      # slot 0 not installed yet: the weights ride along
+            self._pending0 = (self._pending0[0], self._pending0[1], w)
+        else:
+            self.detector.set_class_weights(w)
         self._class_weight = np.asarray(w, dtype=np.float64)
 
     def score_batch(self, d_images, grid_rows: int, grid_cols: int, image_sets=None):
+        if getattr(self, "_pending0", None) is not None and (image_sets is None or 0 in [int(v) for v in image_sets]):
+            self._flush0()
         return self.detector.detect(d_images, grid_rows, grid_cols, score_threshold=0.12, max_dets=50, image_sets=image_sets)
 
     def install_queries(self, slot: int, target_objects: List[str], cue_objects: List[str],

@@ -81,6 +81,7 @@ class OwlScorer:
         self._h = h
         self.max_batch = int(max_batch)
         self.Qs = {}                # query-set slot -> number of queries
+        self._pending = {}          # slot -> (ids, mask, weights) recorded by set_queries(lazy=True), installed on first use
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     @classmethod
@@ -106,17 +107,38 @@ class OwlScorer:
     def Q(self) -> int:
         return self.Qs.get(0, 0)
 
-    def set_queries(self, input_ids: np.ndarray, attention_mask: np.ndarray, class_weight: Sequence[float], slot: int = 0):
+    def set_queries(self, input_ids: np.ndarray, attention_mask: np.ndarray, class_weight: Sequence[float], slot: int = 0,
+                    lazy: bool = False):
+        """Run the text tower on the queries and install them in ``slot``.  ``lazy=True`` only records them (after the checks
+        the library would make): the text tower runs when the slot is first USED -- scored against, read back, re-weighted.
+        A searcher's constructor installs its question in slot 0 like the reference's does (interface_searcher.py:87), but a
+        lock-step group scores every item against its own slot 1..31 and never touches slot 0; the solo path uses it at once."""
         ids = np.ascontiguousarray(input_ids, dtype=np.int32)
         am = np.ascontiguousarray(attention_mask, dtype=np.int32)
         w = np.ascontiguousarray(class_weight, dtype=np.float64)
         Q = ids.shape[0]
         if ids.shape != (Q, W.T_LEN) or am.shape != ids.shape or w.shape != (Q,):
             raise ValueError("set_queries: ids/mask must be [Q,16] and class_weight [Q]")
+        self._pending.pop(int(slot), None)
+        if lazy:
+            if not 1 <= Q <= 32:
+                raise _lib.TStarHipError(f"tstar_owl_set_queries: Q must be in 1..32 (got {Q})")
+            if ids.min() < 0 or ids.max() >= 49408:
+                raise _lib.TStarHipError("tstar_owl_set_queries: token id out of range")
+            self._pending[int(slot)] = (ids.copy(), am.copy(), w.copy())
+            self.Qs[int(slot)] = Q
+            return
         rc = self._lib.tstar_owl_set_queries(self._h, int(slot), ids.ctypes.data, am.ctypes.data, w.ctypes.data, Q,
                                              _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_set_queries")
         self.Qs[int(slot)] = Q
+
+    def _flush(self, slots):
+        """Install the recorded (lazy) queries of the slots about to be used."""
+        for sl in {int(v) for v in slots}:
+            p = self._pending.pop(sl, None)
+            if p is not None:
+                self.set_queries(p[0], p[1], p[2], slot=sl)
 
     def set_queries_many(self, entries):
         """``entries``: [(slot, input_ids [Q,16], attention_mask [Q,16], class_weight [Q])] -- the queries of several slots through
@@ -136,6 +158,7 @@ class OwlScorer:
                                                   w_c.ctypes.data, _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_set_queries_many")
         for sl, q in zip(slots, Qs):
+            self._pending.pop(int(sl), None)
             self.Qs[int(sl)] = int(q)
 
     def set_query_embeds(self, embeds: np.ndarray, query_mask: Sequence[int], class_weight: Sequence[float], slot: int = 0):
@@ -145,6 +168,7 @@ class OwlScorer:
         Q = e.shape[0]
         if e.shape != (Q, W.PROJ) or m.shape != (Q,) or w.shape != (Q,):
             raise ValueError("set_query_embeds: embeds [Q,512], mask [Q], class_weight [Q]")
+        self._pending.pop(int(slot), None)
         rc = self._lib.tstar_owl_set_query_embeds(self._h, int(slot), e.ctypes.data, m.ctypes.data, w.ctypes.data, Q,
                                                   _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_set_query_embeds")
@@ -154,10 +178,15 @@ class OwlScorer:
         w = np.ascontiguousarray(class_weight, dtype=np.float64)
         if w.shape != (self.Qs.get(int(slot), 0),):
             raise ValueError("set_class_weights: one weight per installed query")
+        if int(slot) in self._pending:                       # not installed yet: the weights ride along
+            p = self._pending[int(slot)]
+            self._pending[int(slot)] = (p[0], p[1], w.copy())
+            return
         rc = self._lib.tstar_owl_set_class_weights(self._h, int(slot), w.ctypes.data, len(w), _lib.stream_ptr())
         _lib.check(rc, "tstar_owl_set_class_weights")
 
     def get_query_embeds(self, slot: int = 0) -> np.ndarray:
+        self._flush([slot])
         q = self.Qs.get(int(slot), 0)
         out = np.empty((q, W.PROJ), dtype=np.float32)
         rc = self._lib.tstar_owl_get_query_embeds(self._h, int(slot), out.ctypes.data, q, _lib.stream_ptr())
@@ -191,6 +220,8 @@ class OwlScorer:
             sets = np.ascontiguousarray(image_sets, dtype=np.int32)
             if sets.shape != (B,):
                 raise ValueError("score: image_sets needs one slot per image")
+        if self._pending:
+            self._flush(sets.tolist() if sets is not None else [0])
         if want_logits:
             qs = {self.Qs.get(int(v), 0) for v in (sets if sets is not None else [0])}
             if len(qs) != 1:
