@@ -76,6 +76,10 @@ def parse():
                          "with the OWL-ViT backend, 24 with YOLO-World (its grid forwards run at B = the group size: 57 TFLOP/s at 8, "
                          "72 at 16, 84 at 24, and an iteration's ~228 verification frames fill three full chunks of 76: 12.3 k frames/s "
                          "against 12.05 k at 16 and 12.15 k at 31 in a same-box A/B; run it with --steps 48)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="lock-step groups alternating on the GPU (tstar_amd.lockstep.search_lockstep_groups): while the detector runs "
+                         "one group's verification batch the host does the other group's bookkeeping; one stream of detector work, "
+                         "results identical to running the groups one after another; 1 = one group at a time")
     ap.add_argument("--heuristic", choices=["owl", "yolo"], default="owl",
                     help="detector backend: owl = OWL-ViT-B/32 (configs[1], the headline); yolo = YOLO-World-v2-L on the f32 VALU, no "
                          "MFMA (BASELINE configs[3]; parity of that model is unpinned: its source is not in the reference tree)")
@@ -112,12 +116,19 @@ def make_searcher(heuristic, item, g, k=8):
 
 def run_group(heuristic, items, g, k=8):
     """One lock-step group of independent (video, question) searches (a single search when len(items) == 1)."""
-    from tstar_amd.lockstep import search_lockstep
-    ss = [make_searcher(heuristic, it, g, k) for it in items]
-    if len(ss) == 1:
-        return [(ss[0], ss[0].search()[1])]
-    res = search_lockstep(ss)
-    return [(s_, r[1]) for s_, r in zip(ss, res)]
+    return run_groups(heuristic, [items], g, k)[0]
+
+
+def run_groups(heuristic, groups, g, k=8):
+    """Lock-step groups of independent (video, question) searches, the groups alternating on the GPU
+    (tstar_amd.lockstep.search_lockstep_groups); per group [(searcher, time_stamps)]."""
+    from tstar_amd.lockstep import search_lockstep_groups
+    sss = [[make_searcher(heuristic, it, g, k) for it in items] for items in groups]
+    if len(sss) == 1 and len(sss[0]) == 1:
+        s_ = sss[0][0]
+        return [[(s_, s_.search()[1])]]
+    res = search_lockstep_groups(sss)
+    return [[(s_, r[1]) for s_, r in zip(ss, rr)] for ss, rr in zip(sss, res)]
 
 
 def verify_keyframes(heuristic, item, g, k, timed_keyframes):
@@ -433,8 +444,11 @@ def main():
         """Run one search per item, `conc` lock-step groups at a time; returns per-search (searcher, timestamps, seconds)."""
         q = queue.Queue()
         L = max(1, min(args.lockstep, 31))
-        for i in range(0, len(items), L):
-            q.put((i, items[i:i + L]))
+        PL = max(1, args.pipeline)
+        while PL > 1 and PL * L > 63:             # query-set slots of one detector handle (include/tstar_hip.h)
+            PL -= 1
+        for i in range(0, len(items), L * PL):    # PL lock-step groups alternate on the GPU (tstar_amd.lockstep)
+            q.put((i, [items[j:j + L] for j in range(i, min(i + L * PL, len(items)), L)]))
         out = [None] * len(items)
         errs = []
 
@@ -448,9 +462,9 @@ def main():
                         except queue.Empty:
                             break
                         t1 = time.perf_counter()
-                        grp = run_group(heuristics[w], sd, g, args.search_nframes)
-                        streams[w].synchronize()
-                        for j, (s_, ts_) in enumerate(grp):
+                        grps = run_groups(heuristics[w], sd, g, args.search_nframes)
+                        torch.cuda.synchronize()
+                        for j, (s_, ts_) in enumerate([x for grp in grps for x in grp]):
                             out[i + j] = (s_, ts_, time.perf_counter() - t1)
             except Exception as e:                      # surface worker failures in the main thread
                 errs.append(e)
@@ -604,6 +618,7 @@ def main():
                             f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
                 "workload_kind": workload, "items_total": n_items_total,
                 "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc, "lockstep_items_per_batch": max(1, min(args.lockstep, 31)),
+                "lockstep_groups_alternating": max(1, args.pipeline),
                 "mean_search_latency_sec": latency, "single_search_alone_latency_sec": solo_latency,
                 "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,
                 "detector_images_per_video": images / args.steps, "max_batch": args.yolo_max_batch if args.heuristic == "yolo" else args.max_batch,

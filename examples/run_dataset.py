@@ -38,7 +38,7 @@ def main():
     import torch.distributed as dist
     from tstar_amd.interface_heuristic import initialize_heuristic
     from tstar_amd.interface_searcher import TStarSearcher
-    from tstar_amd.lockstep import search_lockstep
+    from tstar_amd.lockstep import search_lockstep_groups
     from tstar_amd.results import make_result, save_results
     from tstar_amd.sharding import gather_keyframes, interleave_by_item, item_seed, shard_items
 
@@ -53,15 +53,19 @@ def main():
     heuristic = initialize_heuristic("owl-vit", synthetic_seed=0, max_batch=64, device=f"cuda:{local}")
     mine = shard_items(len(items), world, rank)
     rows, dists = [], {}
-    for g0 in range(0, len(mine), args.lockstep):
-        group = mine[g0:g0 + args.lockstep]
-        ss = [TStarSearcher(items[i]["video_path"], heuristic, list(items[i]["targets"]), list(items[i]["cues"]),
-                            search_nframes=args.search_nframes, image_grid_shape=(args.grid, args.grid),
-                            search_budget=1000, confidence_threshold=0.6,
-                            rng=np.random.RandomState(item_seed(args.seed, i)), keep_visual_history=False) for i in group]
-        for i, s, (frames, ts) in zip(group, ss, search_lockstep(ss)):
-            rows.append([int(t) for t in ts])
-            dists[i] = s.P_history[-1] if s.P_history else []
+    # two lock-step groups alternate on the GPU: one group's host bookkeeping runs under the other's verification batch
+    L = max(1, min(args.lockstep, 31))
+    for g0 in range(0, len(mine), 2 * L):
+        groups = [mine[g1:g1 + L] for g1 in range(g0, min(g0 + 2 * L, len(mine)), L)]
+        sss = [[TStarSearcher(items[i]["video_path"], heuristic, list(items[i]["targets"]), list(items[i]["cues"]),
+                              search_nframes=args.search_nframes, image_grid_shape=(args.grid, args.grid),
+                              search_budget=1000, confidence_threshold=0.6,
+                              rng=np.random.RandomState(item_seed(args.seed, i)), keep_visual_history=False) for i in group]
+               for group in groups]
+        for group, ss, res in zip(groups, sss, search_lockstep_groups(sss)):
+            for i, s, (frames, ts) in zip(group, ss, res):
+                rows.append([int(t) for t in ts])
+                dists[i] = s.P_history[-1] if s.P_history else []
     gathered = gather_keyframes(rows, world, pad_to=(len(items) + world - 1) // world)
     if world > 1:
         gathered = interleave_by_item(gathered, len(items), world)

@@ -38,7 +38,7 @@ extern "C" {
 #define TSTAR_OWL_QDIM 512
 #define TSTAR_OWL_TEXT_LEN 16
 #define TSTAR_OWL_MAX_QUERIES 32
-#define TSTAR_OWL_MAX_SETS 32      /* independent query sets (questions) resident at once */
+#define TSTAR_OWL_MAX_SETS 64      /* independent query sets (questions) resident at once */
 
 const char* tstar_last_error(void);
 int tstar_abi_version(void);

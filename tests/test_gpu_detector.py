@@ -270,7 +270,7 @@ def test_install_queries_many_equals_one_by_one():
         assert tx == tm and h.scorer.Qs[slot] == q_many
         assert np.array_equal(h.scorer.get_query_embeds(slot), e_many), slot
         assert torch.equal(h.score_batch(img, 1, 1, image_sets=[slot]).scores, sc), slot
-    with pytest.raises(ValueError, match="slot must be in 1..31"):
+    with pytest.raises(ValueError, match="slot must be in 1..63"):
         h.install_queries_many([(0, ["a"], [], None)])
     # text-only handle: 12 items x 5 queries = 60 sequences > 40 per forward
     y = YoloWorldInterface(synthetic_seed=0, scale="s", max_batch=1)

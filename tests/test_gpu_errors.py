@@ -30,8 +30,8 @@ def test_owl_score_argument_validation(env):
         h.scorer.score(img, 100, 100)
     with pytest.raises(ValueError, match="one slot per image"):
         h.scorer.score(img, 1, 1, image_sets=[0, 0])
-    with pytest.raises(L.TStarHipError, match="query_set must be in 0..31"):
-        h.scorer.score(img, 1, 1, image_sets=[32])
+    with pytest.raises(L.TStarHipError, match="query_set must be in 0..63"):
+        h.scorer.score(img, 1, 1, image_sets=[64])
     r = h.scorer.score(img, 1, 1)                                   # still healthy afterwards
     assert torch.isfinite(r.scores).all()
 

@@ -629,6 +629,56 @@ def test_lockstep_group_equals_sequential_searches():
         search_lockstep([TStarSearcher(stores[0], h, ["a"], [], image_grid_shape=(4, 4))])
 
 
+def test_alternating_lockstep_groups_equal_sequential_searches():
+    """Three lock-step groups ALTERNATING on the GPU (search_lockstep_groups: one group's bookkeeping under the other's
+    verification batch, state kernels on a side stream) against the same items searched one by one: bit-identical
+    keyframes, frames, score distributions, call counts and P.  The groups differ in size, grid and length of their
+    searches, so they fall out of phase and finish at different times; one group keeps its visual history."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.lockstep import search_lockstep_groups
+    from tstar_amd.video import synthetic_video, synthetic_video_nv12
+    rs = np.random.RandomState(4242)
+    objs = ["couch", "tv", "chair", "dog", "ball", "lamp", "cup", "a red car"]
+    h = OWLInterface(synthetic_seed=0, max_batch=16)
+    specs = []
+    for grp, (g, n_items) in enumerate([(4, 3), (2, 5), (3, 1)]):
+        row = []
+        for i in range(n_items):
+            N = int(rs.randint(60, 500))
+            pick = [str(x) for x in rs.permutation(objs)]
+            row.append(dict(store=(synthetic_video_nv12 if rs.rand() < 0.3 else synthetic_video)(N, seed=900 + 10 * grp + i), g=g,
+                            t=pick[:int(rs.randint(1, 4))], c=pick[4:4 + int(rs.randint(0, 3))], K=int(rs.randint(1, 9)),
+                            thr=float(rs.choice([0.004, 0.3, 0.6, 0.95], p=[0.15, 0.25, 0.4, 0.2])), b=float(rs.choice([0.2, 0.4, 0.8])),
+                            seed=int(rs.randint(0, 10000))))
+        specs.append(row)
+
+    def make(sp, keep=False):
+        return TStarSearcher(sp["store"], h, list(sp["t"]), list(sp["c"]), search_nframes=sp["K"], image_grid_shape=(sp["g"], sp["g"]),
+                             search_budget=sp["b"], confidence_threshold=sp["thr"], rng=np.random.RandomState(sp["seed"]),
+                             keep_visual_history=keep)
+
+    seq = []
+    for row in specs:
+        for sp in row:
+            s = make(sp)
+            fr, ts = s.search()
+            seq.append((fr, ts, s.score_distribution, s.frames_scored, s.detector_calls, s.iterations, s.P_history[-1], len(s.P_history)))
+    groups = [[make(sp, keep=(gi == 1)) for sp in row] for gi, row in enumerate(specs)]
+    res = search_lockstep_groups(groups)
+    flat = [(s, r) for ss, rr in zip(groups, res) for s, r in zip(ss, rr)]
+    assert len(flat) == len(seq)
+    for k, ((s, r), e) in enumerate(zip(flat, seq)):
+        assert r[1] == e[1] and np.array_equal(r[0], e[0]), k
+        assert np.array_equal(s.score_distribution, e[2]), k
+        assert (s.frames_scored, s.detector_calls, s.iterations) == e[3:6], k
+        assert s.P_history[-1] == e[6] and len(s.P_history) == e[7], k
+    assert len(groups[1][0].image_grid_iters) > 0
+    assert len({s._slot for s, _ in flat}) == len(flat)                  # every item had its own query-set slot
+    with pytest.raises(ValueError, match="at most 63"):
+        search_lockstep_groups([[make(specs[0][0])] * 40, [make(specs[0][0])] * 24])
+
+
 def test_lockstep_randomized_groups():
     """Three seeded random lock-step groups of 5-7 heterogeneous items (video length and storage format, K, threshold,
     budget, one to three targets, cues; the grid is common to a group) against the same items searched one by one: the

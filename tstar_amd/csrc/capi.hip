@@ -322,7 +322,7 @@ int tstar_owl_destroy(tstar_owl* h) {
     return TSTAR_OK;
 }
 
-#define CHECK_SET(set, fn) TSTAR_REQUIRE((set) >= 0 && (set) < TSTAR_OWL_MAX_SETS, fn ": query_set must be in 0..31")
+#define CHECK_SET(set, fn) TSTAR_REQUIRE((set) >= 0 && (set) < TSTAR_OWL_MAX_SETS, fn ": query_set must be in 0..63")
 
 static int finish_queries(tstar_owl* h, int set, const uint8_t* h_mask, const double* h_w, int Q, hipStream_t s) {
     const size_t qo = (size_t)set * TSTAR_OWL_MAX_QUERIES;
@@ -377,7 +377,7 @@ int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_ids, con
 int tstar_owl_set_queries_many(tstar_owl* h, int n_sets, const int32_t* h_sets, const int32_t* h_Q, const int32_t* h_ids, const int32_t* h_am,
                                const double* h_w, void* stream) {
     TSTAR_REQUIRE(h && h_sets && h_Q && h_ids && h_am && h_w, "tstar_owl_set_queries_many: null argument");
-    TSTAR_REQUIRE(n_sets >= 1 && n_sets <= TSTAR_OWL_MAX_SETS, "tstar_owl_set_queries_many: n_sets must be in 1..32");
+    TSTAR_REQUIRE(n_sets >= 1 && n_sets <= TSTAR_OWL_MAX_SETS, "tstar_owl_set_queries_many: n_sets must be in 1..64");
     if (!h->has_text) { set_error("tstar_owl_set_queries_many: handle was created without text weights"); return TSTAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
     int total = 0;

@@ -1415,7 +1415,7 @@ int tstar_yolo_create(tstar_yolo** out, const float* h_blob, size_t n_blob, cons
     return TSTAR_OK;
 }
 
-#define YCHECK_SET(set, fn) TSTAR_REQUIRE((set) >= 0 && (set) < YOLO_SETS, fn ": query_set must be in 0..31")
+#define YCHECK_SET(set, fn) TSTAR_REQUIRE((set) >= 0 && (set) < YOLO_SETS, fn ": query_set must be in 0..63")
 
 int tstar_yolo_set_text_feats(tstar_yolo* h, int query_set, const float* h_text, const double* h_class_weight, int Q, void* stream) {
     TSTAR_REQUIRE(h && h_text && h_class_weight, "tstar_yolo_set_text_feats: null argument");

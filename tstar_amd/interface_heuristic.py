@@ -167,11 +167,11 @@ class OWLInterface(HeuristicInterface):
 
     def install_queries(self, slot: int, target_objects: List[str], cue_objects: List[str],
                         object2weight: Optional[Dict[str, float]] = None) -> List[List[str]]:
-        """Install a question's queries in slot 1..31 WITHOUT touching ``self.texts`` (slot 0 is what
+        """Install a question's queries in slot 1..63 WITHOUT touching ``self.texts`` (slot 0 is what
         ``reparameterize_object_list`` manages).  Several (video, question) items can then be scored in
         one batch, each image against its own slot.  Returns the texts list of the slot."""
-        if not 1 <= int(slot) <= 31:
-            raise ValueError("install_queries: slot must be in 1..31")
+        if not 1 <= int(slot) <= 63:
+            raise ValueError("install_queries: slot must be in 1..63")
         texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
         ids, am = encode_queries(texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
         o2w = dict(object2weight or {})
@@ -183,8 +183,8 @@ class OWLInterface(HeuristicInterface):
         return texts
 
     def _query_entry(self, slot, target_objects, cue_objects, object2weight):
-        if not 1 <= int(slot) <= 31:
-            raise ValueError("install_queries: slot must be in 1..31")
+        if not 1 <= int(slot) <= 63:
+            raise ValueError("install_queries: slot must be in 1..63")
         texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
         ids, am = encode_queries(texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
         o2w = dict(object2weight or {})
@@ -379,8 +379,8 @@ class YoloWorldInterface(HeuristicInterface):
 
     def install_queries(self, slot: int, target_objects: List[str], cue_objects: List[str],
                         object2weight: Optional[Dict[str, float]] = None) -> List[List[str]]:
-        if not 1 <= int(slot) <= 31:
-            raise ValueError("install_queries: slot must be in 1..31")
+        if not 1 <= int(slot) <= 63:
+            raise ValueError("install_queries: slot must be in 1..63")
         texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
         o2w = dict(object2weight or {})
         for o in target_objects:
@@ -395,8 +395,8 @@ class YoloWorldInterface(HeuristicInterface):
         the same slot numbers; each slot's normalised text features then go to the detector's guide layers)."""
         out, entries, weights = [], [], []
         for slot, target_objects, cue_objects, object2weight in items:
-            if not 1 <= int(slot) <= 31:
-                raise ValueError("install_queries: slot must be in 1..31")
+            if not 1 <= int(slot) <= 63:
+                raise ValueError("install_queries: slot must be in 1..63")
             texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
             o2w = dict(object2weight or {})
             for o in target_objects:

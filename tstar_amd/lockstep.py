@@ -8,6 +8,15 @@ sampler stream, device state and sequential ``remaining_targets`` logic.  Result
 running the items one by one with the same per-item RNGs; the GPU sees larger GEMMs (M = sum of the
 items' images x 577), fewer launches and fewer synchronisation points per item, and the items' host-side
 FITPACK fits run side by side in worker processes (tstar_amd.spline_pool).
+
+Two (or more) lock-step groups can be ALTERNATED on the one GPU (``search_lockstep_groups``): while the
+detector works on one group's verification batch, the host does the other group's bookkeeping (replay of
+its verification results, score write-back, histories, next iteration's samples) and queues that group's
+grid forward behind it.  Every group runs exactly the statements it would run alone, in the same order, so
+results do not change; what changes is that the detector stream only drains for the short step between a
+group's grid forward and its verification batch.  For that the small per-item state kernels and their
+read-backs (``tstar_searcher_*``) go to a side stream: a read-back on the detector stream would wait for
+everything queued behind it by the other group.
 """
 from __future__ import annotations
 
@@ -18,96 +27,189 @@ import numpy as np
 from . import spline_pool
 from .interface_searcher import TStarSearcher
 
-MAX_GROUP = 31          # TSTAR_OWL_MAX_SETS - 1 query-set slots (include/tstar_hip.h)
+MAX_GROUP = 63          # TSTAR_OWL_MAX_SETS - 1 query-set slots (include/tstar_hip.h); slot 0 stays the heuristic's own
+
+_SIDE = {}              # device index -> the side stream of the searcher-state kernels
 
 
-def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray, list]]:
-    """Run ``search()`` of every searcher in lock-step; returns [(frames, time_stamps)] in input order.
+def _side_stream(torch):
+    d = torch.cuda.current_device()
+    if d not in _SIDE:
+        _SIDE[d] = torch.cuda.Stream(device=d)
+    return _SIDE[d]
 
-    All searchers must share one tstar_amd ``OWLInterface`` (fast path), use the same grid shape and
-    carry their own ``rng`` (with the process-global numpy generator the draw order would depend on the
-    interleaving, unlike sequential runs).  At most 31 items at a time (query-set slots 1..31; slot 0 stays the heuristic's own)."""
-    import torch
-    if not searchers:
-        return []
-    if len(searchers) > MAX_GROUP:
-        raise ValueError(f"search_lockstep: at most {MAX_GROUP} items per lock-step group")
-    h = searchers[0].heuristic
-    shape = tuple(searchers[0].image_grid_shape)
-    for s in searchers:
-        if s.heuristic is not h or not s._fast:
-            raise ValueError("search_lockstep: all searchers must share one tstar_amd OWLInterface")
-        if tuple(s.image_grid_shape) != shape:
-            raise ValueError("search_lockstep: all searchers must use the same image_grid_shape")
-        if s._rng is None:
-            raise ValueError("search_lockstep: every searcher needs its own rng= (a seeded RandomState)")
-    rows, cols = shape
-    n = rows * cols
-    for i, s in enumerate(searchers):
-        s._slot = i + 1
-    if hasattr(h, "install_queries_many"):                   # one text-tower forward for the whole group's questions
-        texts = h.install_queries_many([(s._slot, s.target_objects, s.cue_objects, s.object2weight) for s in searchers])
-        for s, t in zip(searchers, texts):
-            s._texts = t
-    else:
-        for s in searchers:
-            s._texts = h.install_queries(s._slot, s.target_objects, s.cue_objects, s.object2weight)
 
-    def active():
-        return [s for s in searchers if s.remaining_targets and s.search_budget > 0]
+class _Group:
+    """One lock-step group: the statements of an iteration cut at the two points where the host has to wait for
+    the detector (grid forward, verification batch)."""
 
-    act = active()
-    while act:
+    def __init__(self, searchers: Sequence[TStarSearcher], first_slot: int, torch):
+        self.torch = torch
+        self.ss = list(searchers)
+        self.h = self.ss[0].heuristic
+        self.rows, self.cols = tuple(self.ss[0].image_grid_shape)
+        self.n = self.rows * self.cols
+        for i, s in enumerate(self.ss):
+            s._slot = first_slot + i
+        self.main = torch.cuda.current_stream()
+        self.side = _side_stream(torch)
+        self.pending = None            # the verification batch in flight (end() consumes it)
+        self.act = []
+
+    def install(self):
+        h = self.h
+        self.side.wait_stream(self.main)          # state written on the caller's stream before the search (once: a wait per
+                                                  # iteration would queue the samples behind the other group's batch)
+        if hasattr(h, "install_queries_many"):                   # one text-tower forward for the whole group's questions
+            texts = h.install_queries_many([(s._slot, s.target_objects, s.cue_objects, s.object2weight) for s in self.ss])
+            for s, t in zip(self.ss, texts):
+                s._texts = t
+        else:
+            for s in self.ss:
+                s._texts = h.install_queries(s._slot, s.target_objects, s.cue_objects, s.object2weight)
+        self.act = self._active()
+
+    def _active(self):
+        return [s for s in self.ss if s.remaining_targets and s.search_budget > 0]
+
+    def begin(self):
+        """Samples of the iteration (state kernels, side stream), grid images and the grid forward (detector stream)."""
+        torch = self.torch
         secs_l, grids = [], []
-        for s in act:
-            secs = s._sample_secs(n)
-            s.search_budget -= n
-            secs_l.append(secs)
+        with torch.cuda.stream(self.side):
+            for s in self.act:
+                secs_l.append(s._sample_secs(self.n))
+                s.search_budget -= self.n
+        for s, secs in zip(self.act, secs_l):
             grids.append(s._device_grid(secs))
-        res = h.score_batch(torch.stack(grids), rows, cols, image_sets=[s._slot for s in act])
-        masks = res.cell_mask.cpu().numpy().astype(np.uint32)
+        self.secs_l, self.grids = secs_l, grids
+        self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=[s._slot for s in self.act])
+        self.ev_grid = torch.cuda.Event()
+        self.ev_grid.record(self.main)
+
+    def middle(self):
+        """Wait for the grid forward; the verification batch (detector stream) and, under its shadow, the score write-back
+        (side stream), the FITPACK fits, P and the histories."""
+        torch, h, act, res, secs_l, n = self.torch, self.h, self.act, self.res, self.secs_l, self.n
         names_l, fits, cand_l = [], [], []
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_grid)
+            masks = res.cell_mask.cpu().numpy().astype(np.uint32)
         for i, s in enumerate(act):
-            s.device_images_scored += 1
             names = [s._names_from_mask(int(m)) for m in masks[i][:len(secs_l[i])]]
             names_l.append(names)
-            if s.keep_visual_history:
-                imgs, dets = h.annotated_batch(grids[i].unsqueeze(0), res, i, 1)
-                s.image_grid_iters.append([imgs[0]])
-                s.detect_annotot_iters.append([imgs[0]])
-                s.detect_bbox_iters.append(dets)
-            s.frames_scored += n
-            s.detector_calls += 1
-            fits.append(s._state.apply_grid(secs_l[i], res.cell_conf[i]))
             cand_l.append([j for j, nm in enumerate(names) if any(t in nm for t in s.remaining_targets)])
-        # ONE verification batch for every item of the group (device work only) ...
+        # ONE verification batch for every item of the group (device work only), queued before anything else: it needs the
+        # cell masks only, and the detector stream is empty until it arrives ...
         vres = vframes = None
         offs = np.cumsum([0] + [len(c) for c in cand_l])
+        ev = None
         if offs[-1] > 0:
             vframes = torch.cat([s._device_verify_frames([secs_l[i][j] for j in cand_l[i]])
                                  for i, s in enumerate(act) if cand_l[i]])
             sets = [s._slot for i, s in enumerate(act) for _ in cand_l[i]]
             vres = h.score_batch(vframes, 1, 1, image_sets=sets)
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+        # ... then the grid scores go into the per-item state (write-back, window spread, visited list: side stream) ...
+        with torch.cuda.stream(self.side):
+            for i, s in enumerate(act):
+                s.device_images_scored += 1
+                if s.keep_visual_history:
+                    imgs, dets = h.annotated_batch(self.grids[i].unsqueeze(0), res, i, 1)
+                    s.image_grid_iters.append([imgs[0]])
+                    s.detect_annotot_iters.append([imgs[0]])
+                    s.detect_bbox_iters.append(dets)
+                s.frames_scored += n
+                s.detector_calls += 1
+                fits.append(s._state.apply_grid(secs_l[i], res.cell_conf[i]))
         # ... while the host builds the sampling distributions (FITPACK fit + sigmoid, interface_searcher.py:262-274):
         # one worker process per item (tstar_amd.spline_pool), same scipy / numpy calls, bit-identical P
-        for s, P in zip(act, spline_pool.distribution_many(fits, [a.total_frame_num for a in act], s=0.5)):
-            s._state.write(2, P)
-        for s in act:
-            s.store_score_distribution()
+        with torch.cuda.stream(self.side):
+            for s, P in zip(act, spline_pool.distribution_many(fits, [a.total_frame_num for a in act], s=0.5)):
+                s._state.write(2, P)
+            for s in act:
+                s.store_score_distribution()
+        self.pending = (vres, vframes, ev, cand_l, offs, names_l)
+
+    def end(self):
+        """Wait for the verification batch; the sequential ``remaining_targets`` replay and its score overwrites."""
+        if self.pending is None:
+            return
+        torch = self.torch
+        vres, vframes, ev, cand_l, offs, names_l = self.pending
+        self.pending = None
+        act, secs_l = self.act, self.secs_l
         if vres is not None:
-            vconf = vres.cell_conf[:, 0].cpu().numpy()
-            vmask = vres.cell_mask[:, 0].cpu().numpy().astype(np.uint32)
-            for i, s in enumerate(act):
-                if cand_l[i]:
-                    s.device_images_scored += len(cand_l[i])
-                    s._verify_replay(cand_l[i], vconf[offs[i]:offs[i + 1]], vmask[offs[i]:offs[i + 1]], secs_l[i],
-                                     names_l[i], vframes, vres, int(offs[i]))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                vconf = vres.cell_conf[:, 0].cpu().numpy()
+                vmask = vres.cell_mask[:, 0].cpu().numpy().astype(np.uint32)
+                for i, s in enumerate(act):
+                    if cand_l[i]:
+                        s.device_images_scored += len(cand_l[i])
+                        s._verify_replay(cand_l[i], vconf[offs[i]:offs[i + 1]], vmask[offs[i]:offs[i + 1]], secs_l[i],
+                                         names_l[i], vframes, vres, int(offs[i]))
         for s in act:
             s.iterations += 1
-        act = active()
-    out = []
-    for s in searchers:
-        frames, ts = s.pop_frames(video_path=s.video_path, num_samples=s.search_nframes)
-        s.last_time_stamps = list(ts)
-        out.append((frames, ts))
-    return out
+        self.res = self.grids = None
+        self.act = self._active()
+
+    def finish(self):
+        torch = self.torch
+        out = []
+        with torch.cuda.stream(self.side):
+            for s in self.ss:
+                frames, ts = s.pop_frames(video_path=s.video_path, num_samples=s.search_nframes)
+                s.last_time_stamps = list(ts)
+                out.append((frames, ts))
+        self.main.wait_stream(self.side)          # whoever uses the searchers next on this stream sees the final state
+        return out
+
+
+def search_lockstep_groups(groups: Sequence[Sequence[TStarSearcher]]) -> List[List[Tuple[np.ndarray, list]]]:
+    """Run ``search()`` of every searcher, each inner list as one lock-step group, the groups alternating on the GPU
+    (see the module docstring); returns, per group, [(frames, time_stamps)] in input order.
+
+    All searchers must share one tstar_amd detector interface (fast path), the searchers of a group the same grid
+    shape, and every searcher carries its own ``rng`` (with the process-global numpy generator the draw order would
+    depend on the interleaving, unlike sequential runs).  At most 63 items in total (query-set slots 1..63)."""
+    import torch
+    groups = [list(g) for g in groups if len(g)]
+    if not groups:
+        return []
+    if sum(len(g) for g in groups) > MAX_GROUP:
+        raise ValueError(f"search_lockstep: at most {MAX_GROUP} items in flight (query-set slots)")
+    h = groups[0][0].heuristic
+    for g in groups:
+        shape = tuple(g[0].image_grid_shape)
+        for s in g:
+            if s.heuristic is not h or not s._fast:
+                raise ValueError("search_lockstep: all searchers must share one tstar_amd OWLInterface")
+            if tuple(s.image_grid_shape) != shape:
+                raise ValueError("search_lockstep: all searchers must use the same image_grid_shape")
+            if s._rng is None:
+                raise ValueError("search_lockstep: every searcher needs its own rng= (a seeded RandomState)")
+    gs, slot = [], 1
+    for g in groups:
+        gs.append(_Group(g, slot, torch))
+        slot += len(g)
+    for g in gs:
+        g.install()
+    live = [g for g in gs if g.act]
+    while live:
+        for g in list(live):
+            g.end()                    # nothing on the first pass; otherwise the other groups' work has covered the wait
+            if not g.act:
+                live.remove(g)
+                continue
+            g.begin()
+            g.middle()
+    return [g.finish() for g in gs]
+
+
+def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray, list]]:
+    """Run ``search()`` of every searcher in lock-step (one group); returns [(frames, time_stamps)] in input order."""
+    if not searchers:
+        return []
+    return search_lockstep_groups([searchers])[0]

@@ -112,7 +112,7 @@ class OwlScorer:
         """Run the text tower on the queries and install them in ``slot``.  ``lazy=True`` only records them (after the checks
         the library would make): the text tower runs when the slot is first USED -- scored against, read back, re-weighted.
         A searcher's constructor installs its question in slot 0 like the reference's does (interface_searcher.py:87), but a
-        lock-step group scores every item against its own slot 1..31 and never touches slot 0; the solo path uses it at once."""
+        lock-step group scores every item against its own slot 1..63 and never touches slot 0; the solo path uses it at once."""
         ids = np.ascontiguousarray(input_ids, dtype=np.int32)
         am = np.ascontiguousarray(attention_mask, dtype=np.int32)
         w = np.ascontiguousarray(class_weight, dtype=np.float64)
