@@ -96,9 +96,13 @@ class _Group:
             self.side.wait_event(self.ev_grid)
             masks = res.cell_mask.cpu().numpy().astype(np.uint32)
         for i, s in enumerate(act):
-            names = [s._names_from_mask(int(m)) for m in masks[i][:len(secs_l[i])]]
-            names_l.append(names)
-            cand_l.append([j for j, nm in enumerate(names) if any(t in nm for t in s.remaining_targets)])
+            # candidates of the verification batch: cells whose mask lists a remaining target (the same test as
+            # ``any(t in names ...)`` on the decoded names, which are only needed by the replay and are built below)
+            tb = 0
+            for q, t in enumerate(s._texts):
+                if t[0] in s.remaining_targets:
+                    tb |= 1 << q
+            cand_l.append(np.nonzero(masks[i][:len(secs_l[i])] & np.uint32(tb))[0].tolist())
         # ONE verification batch for every item of the group (device work only), queued before anything else: it needs the
         # cell masks only, and the detector stream is empty until it arrives ...
         vres = vframes = None
@@ -114,6 +118,7 @@ class _Group:
         # ... then the grid scores go into the per-item state (write-back, window spread, visited list: side stream) ...
         with torch.cuda.stream(self.side):
             for i, s in enumerate(act):
+                names_l.append([s._names_from_mask(int(m)) for m in masks[i][:len(secs_l[i])]])
                 s.device_images_scored += 1
                 if s.keep_visual_history:
                     imgs, dets = h.annotated_batch(self.grids[i].unsqueeze(0), res, i, 1)
