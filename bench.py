@@ -553,7 +553,14 @@ def main():
     _lib.check(lib.tstar_prof_read_bytes(2 if args.heuristic == "yolo" else 0, C.byref(by)))
     a_l, a_ms, a_fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
     _lib.check(lib.tstar_prof_read(1, C.byref(a_l), C.byref(a_ms), C.byref(a_fl)))
+    # every launch of the two categories (sampled or not): count and algorithmic flops, exact.  A category's time share is
+    # all-launch flops / (sampled flops / sampled ms) / wall: launch durations span 13 us .. 4 ms, so sampled ms x stride
+    # carries the +-5 % error of a 1-in-5 sample of them, while flops / ms is nearly the same for every large launch
+    n_all, fl_all, a_all, a_fl_all = C.c_longlong(0), C.c_double(0), C.c_longlong(0), C.c_double(0)
+    _lib.check(lib.tstar_prof_read_totals(2 if args.heuristic == "yolo" else 0, C.byref(n_all), C.byref(fl_all)))
+    _lib.check(lib.tstar_prof_read_totals(1, C.byref(a_all), C.byref(a_fl_all)))
     _lib.check(lib.tstar_prof_enable(0))
+    share = lambda f_all, f_s, ms_s: (f_all / (f_s / (ms_s * 1e-3)) / dt / max(conc, 1)) if f_s > 0 and ms_s > 0 else 0.0
     achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     # HBM-side traffic of the same kernel: rocprofv3 PMC passes of this command cannot run inside the
     # timed process, so the per-launch figure measured with `tools/rocpd_traffic.py` is read from the
@@ -647,9 +654,11 @@ def main():
                 # channels + output channels + weights + fused residual / gate), averaged over the same sampled launches
                 "algorithmic_bytes_per_launch": by.value / max(n_l.value, 1),
                 "traffic_over_algorithmic": (traffic / (by.value / n_l.value)) if traffic and by.value > 0 and n_l.value else None,
-                "time_share_of_step": ms.value * PROF_STRIDE * 1e-3 / dt / max(conc, 1),
+                "launches_total": n_all.value, "gflop_total": fl_all.value / 1e9,
+                "time_share_of_step": share(fl_all.value, fl.value, ms.value),
                 "attention_f32_kernel": {"achieved": (a_fl.value / (a_ms.value * 1e-3) / 1e12) if a_ms.value > 0 else 0.0,
-                                         "launches_timed": a_l.value, "time_share_of_step": a_ms.value * PROF_STRIDE * 1e-3 / dt / max(conc, 1)},
+                                         "launches_timed": a_l.value, "launches_total": a_all.value,
+                                         "time_share_of_step": share(a_fl_all.value, a_fl.value, a_ms.value)},
             },
         }
         if args.heuristic == "yolo":

@@ -318,6 +318,9 @@ int tstar_prof_enable(int on);
 int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops);
 /* algorithmic HBM bytes of the launches tstar_prof_read counted (operands read once, results written once) */
 int tstar_prof_read_bytes(int category, double* total_bytes);
+/* EVERY launch of the category since enable(), sampled or not: their number and their algorithmic flops (exact; with the
+ * sampled launches' flops / ms this gives the category's time without the sampling error of a 1-in-n sample of durations) */
+int tstar_prof_read_totals(int category, long long* launches_all, double* flops_all);
 /* trace markers: enqueue an empty kernel named prof_mark_begin_kernel (which = 0) / prof_mark_end_kernel (1) on `stream`,
  * so that a rocprofv3 kernel trace can be cut to the bracketed region on the GPU's own timeline */
 int tstar_prof_mark(int which, void* stream);

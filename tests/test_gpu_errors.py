@@ -130,6 +130,10 @@ def test_round3_entry_points_validate_their_arguments(env):
     n, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
     L.check(lib.tstar_prof_read(0, C.byref(n), C.byref(ms), C.byref(fl)))
     L.check(lib.tstar_prof_read_bytes(0, C.byref(by)))
+    na, fa = C.c_longlong(0), C.c_double(0)
+    L.check(lib.tstar_prof_read_totals(0, C.byref(na), C.byref(fa)))
+    assert lib.tstar_prof_read_totals(9, C.byref(na), C.byref(fa)) == 1
+    assert na.value == 2 and fa.value == fl.value                                         # stride 1: every launch is sampled
     L.check(lib.tstar_prof_enable(0))
     assert n.value == 2 and fl.value == 2 * 2.0 * 256 * 128 * 64
     assert by.value == 2 * (4.0 * 256 * 64 + 2.0 * 128 * 64 + 4.0 * 256 * 128)            # A (f32) + W (bf16) + C, per launch

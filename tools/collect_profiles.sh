@@ -17,8 +17,8 @@ PY="python $ROOT/bench.py"
 : > "$OUT/bench.err"
 $PY --steps 32 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
-$PY --steps 4 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
-$PY --steps 4 --warmup 1 --weights bf16_exact --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5_exact_split.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16_exact --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5_exact_split.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --workload haystack --no-cpu-baseline > "$OUT/${TAG}_bench_haystack_1gpu.json" 2>> "$OUT/bench.err"
 $PY --workload haystack32 --no-cpu-baseline > "$OUT/${TAG}_bench_haystack32_1gpu.json" 2>> "$OUT/bench.err"

@@ -78,6 +78,7 @@ SIGNATURES = {
     "tstar_prof_enable": (_i, [_i]),
     "tstar_prof_read": (_i, [_i, _vp, _vp, _vp]),
     "tstar_prof_read_bytes": (_i, [_i, _vp]),
+    "tstar_prof_read_totals": (_i, [_i, _vp, _vp]),
     "tstar_prof_mark": (_i, [_i, _vp]),
 }
 

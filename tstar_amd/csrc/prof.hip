@@ -13,6 +13,7 @@ static Cat g_cat[PROF_NCAT];
 static bool g_on = false;
 static int g_stride = 1;            // time every g_stride-th launch of a category
 static long g_seen[PROF_NCAT] = {0, 0, 0};
+static double g_work_all[PROF_NCAT] = {0, 0, 0};      // algorithmic work of EVERY launch since enable (sampled or not)
 static std::mutex g_mu;      // searches may run on several host threads / streams
 
 bool prof_enabled() { return g_on; }
@@ -37,6 +38,7 @@ void prof_start(int cat, hipStream_t s, double work, double bytes) {
     // index): a fixed phase aliases with the launch pattern -- a YOLO search iteration of five forwards of 107 convolutions
     // each made a stride of 5 sample every layer from the same forward (batch size) every time, 3 % off the all-launch average
     const long idx = g_seen[cat]++;
+    g_work_all[cat] += work;
     const unsigned long long blk = (unsigned long long)(idx / g_stride);
     const int pick = (int)(((blk * 0x9E3779B97F4A7C15ull) >> 33) % (unsigned long long)g_stride);
     if ((int)(idx % g_stride) != pick) return;            // not sampled: prof_stop sees no pending event
@@ -70,7 +72,7 @@ int tstar_prof_enable(int on) {
     g_on = on != 0;
     g_stride = on > 1 ? on : 1;
     for (int i = 0; i < PROF_NCAT; ++i) {
-        g_seen[i] = 0; drain(g_cat[i]); g_cat[i].launches = 0; g_cat[i].ms = 0; g_cat[i].work = 0; g_cat[i].bytes = 0; }
+        g_seen[i] = 0; g_work_all[i] = 0; drain(g_cat[i]); g_cat[i].launches = 0; g_cat[i].ms = 0; g_cat[i].work = 0; g_cat[i].bytes = 0; }
     return TSTAR_OK;
 }
 int tstar_prof_read(int category, long long* launches, double* total_ms, double* total_flops) {
@@ -78,6 +80,12 @@ int tstar_prof_read(int category, long long* launches, double* total_ms, double*
     std::lock_guard<std::mutex> lk(g_mu);
     drain(g_cat[category]);
     *launches = g_cat[category].launches; *total_ms = g_cat[category].ms; *total_flops = g_cat[category].work;
+    return TSTAR_OK;
+}
+int tstar_prof_read_totals(int category, long long* launches_all, double* flops_all) {
+    TSTAR_REQUIRE(category >= 0 && category < PROF_NCAT && launches_all && flops_all, "tstar_prof_read_totals: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    *launches_all = g_seen[category]; *flops_all = g_work_all[category];
     return TSTAR_OK;
 }
 int tstar_prof_read_bytes(int category, double* total_bytes) {
