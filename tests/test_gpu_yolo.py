@@ -295,3 +295,45 @@ def test_search_replay_randomized():
         for i in range(s.iterations):
             assert np.array_equal(np.asarray(s.P_history[i]), ref.P_history[i]), (case, i)
         print(f"case {case}: N={N} g={g} K={K} thr={thr} budget={budget} {targets} {cues}: {s.iterations} iterations, keyframes {ts_ref}")
+
+
+def test_alternating_lockstep_groups_on_the_yolo_backend():
+    """Two lock-step groups alternating on the GPU with the YOLO-World backend (scale S) against the same items searched one
+    by one: the same keyframes, score distributions, call counts and P, bit for bit (the group's questions go through one
+    text-tower forward, the constructor's slot-0 install stays pending, candidates come from the cell bitmasks)."""
+    from tstar_amd.interface_heuristic import initialize_heuristic
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.lockstep import search_lockstep_groups
+    from tstar_amd.video import synthetic_video
+    rs = np.random.RandomState(31337)
+    objs = ["couch", "tv", "chair", "dog", "ball", "lamp", "cup"]
+    h = initialize_heuristic("yolo-World", synthetic_seed=1, scale="s", max_batch=16)
+    specs = []
+    for grp, (g, n_items) in enumerate([(3, 4), (4, 3)]):
+        row = []
+        for i in range(n_items):
+            pick = [str(x) for x in rs.permutation(objs)]
+            row.append(dict(store=synthetic_video(int(rs.randint(60, 400)), seed=700 + 10 * grp + i), g=g, t=pick[:int(rs.randint(1, 3))],
+                            c=pick[3:3 + int(rs.randint(0, 3))], K=int(rs.randint(1, 7)), thr=float(rs.choice([0.05, 0.3, 0.6])),
+                            b=float(rs.choice([0.2, 0.5])), seed=int(rs.randint(0, 10000))))
+        specs.append(row)
+
+    def make(sp):
+        return TStarSearcher(sp["store"], h, list(sp["t"]), list(sp["c"]), search_nframes=sp["K"], image_grid_shape=(sp["g"], sp["g"]),
+                             search_budget=sp["b"], confidence_threshold=sp["thr"], rng=np.random.RandomState(sp["seed"]),
+                             keep_visual_history=False)
+
+    seq = []
+    for row in specs:
+        for sp in row:
+            s = make(sp)
+            fr, ts = s.search()
+            seq.append((fr, ts, s.score_distribution, s.frames_scored, s.detector_calls, s.iterations, s.P_history[-1]))
+    groups = [[make(sp) for sp in row] for row in specs]
+    res = search_lockstep_groups(groups)
+    flat = [(s, r) for ss, rr in zip(groups, res) for s, r in zip(ss, rr)]
+    for k, ((s, r), e) in enumerate(zip(flat, seq)):
+        assert r[1] == e[1] and np.array_equal(r[0], e[0]), k
+        assert np.array_equal(s.score_distribution, e[2]), k
+        assert (s.frames_scored, s.detector_calls, s.iterations) == e[3:6], k
+        assert s.P_history[-1] == e[6], k
