@@ -210,6 +210,27 @@ def test_spline_pool_distribution_matches_reference_statements(monkeypatch):
     assert all(np.array_equal(a, b) for a, b in zip(same, got))
     with pytest.raises(ValueError):
         spline_pool.distribution_many(probs, lens[:2])
+    # the asynchronous form (a search running alone starts its fit, enqueues the verification batch, then collects P):
+    # without a pool it computes at wait(); with one, in a worker -- the same P either way, also for ONE problem and for
+    # "nothing visited yet", and the caller's buffers may be overwritten between the two calls
+    assert all(np.array_equal(a, b) for a, b in zip(spline_pool.distribution_async(probs, lens)(), got))
+    monkeypatch.setenv("TSTAR_SPLINE_WORKERS", "2")
+    monkeypatch.setattr(spline_pool, "_pool", None)
+    try:
+        x0, y0 = probs[0][0].copy(), probs[0][1].copy()
+        wait = spline_pool.distribution_async([(x0, y0)], lens[:1])
+        x0[:] = 0
+        y0[:] = 0
+        assert np.array_equal(wait()[0], got[0])
+        assert all(np.array_equal(a, b) for a, b in zip(spline_pool.distribution_async(probs[:2], lens[:2])(), got[:2]))
+        assert all(np.array_equal(a, b) for a, b in zip(spline_pool.distribution_async(probs, lens)(), got))       # 3 problems, 2 workers
+        assert np.array_equal(spline_pool.distribution_async([(np.array([], int), np.array([]))], [7])()[0], np.ones(7) / 7)
+        assert spline_pool.distribution_many(probs[:2], lens[:2])[1].shape == (lens[1],)                          # the pool is free again
+    finally:
+        if spline_pool._pool is not None:
+            spline_pool._pool.close()
+        monkeypatch.setattr(spline_pool, "_pool", None)
+        monkeypatch.setattr(spline_pool, "_pool_failed", False)
 
 
 def test_spline_pool_matches_in_process_fit(monkeypatch):

@@ -394,9 +394,19 @@ class TStarSearcher:
         not read P, and its score overwrites are applied after the histories are stored, exactly
         in the reference's order)."""
         vx, vy = self._state.apply_grid(secs, d_conf)
-        ctx = overlap() if overlap is not None else None
-        # FITPACK fit, evaluation, sigmoid and normalisation on the host with the reference's own calls (:262-274)
-        self._state.write(2, spline_distribution(vx, vy, self.total_frame_num))
+        # FITPACK fit, evaluation, sigmoid and normalisation on the host with the reference's own calls (:262-274).  With a
+        # verification batch to enqueue the fit starts FIRST, in a worker process (tstar_amd.spline_pool: the same scipy
+        # call, bit-identical P): it is the longest step of an iteration of a search running alone (15-60 ms at 4x4), and
+        # the 3-5 ms the host needs to enqueue the batch then run beside it instead of before it
+        if overlap is not None:
+            from . import spline_pool
+            wait = spline_pool.distribution_async([(vx, vy)], [self.total_frame_num])
+            ctx = overlap()
+            P = wait()[0]
+        else:
+            ctx = None
+            P = spline_distribution(vx, vy, self.total_frame_num)
+        self._state.write(2, P)
         self.store_score_distribution()
         return ctx
 

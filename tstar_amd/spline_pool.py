@@ -124,6 +124,33 @@ class SplinePool:
         return out
 
 
+    def begin(self, problems: Sequence[Tuple[np.ndarray, np.ndarray]], s: float, n_frames: Sequence[int]) -> int:
+        """Hand at most len(self) problems to the workers and return at once (the pool stays locked until ``end``)."""
+        if len(problems) > len(self._procs) or len(n_frames) != len(problems):
+            raise ValueError("SplinePool.begin: at most one problem per worker, one n_frames per problem")
+        self._lock.acquire()
+        try:
+            if not self._procs:
+                raise SplinePoolError("spline pool is closed")
+            for p, (x, y), n in zip(self._procs, problems, n_frames):
+                self._send(p, x, y, s, n)
+        except BaseException:
+            self.close()
+            self._lock.release()
+            raise
+        return len(problems)
+
+    def end(self, count: int):
+        """The replies of the ``begin`` before, in input order."""
+        try:
+            return [self._recv(p) for p in self._procs[:count]]
+        except (OSError, SplinePoolError):
+            self.close()
+            raise
+        finally:
+            self._lock.release()
+
+
 _pool: Optional[SplinePool] = None
 _pool_failed = False
 
@@ -183,3 +210,34 @@ def distribution_many(problems: Sequence[Tuple[np.ndarray, np.ndarray]], n_frame
         return out
     from .spline_worker import spline_distribution
     return [spline_distribution(x, y, n, s) for (x, y), n in zip(problems, nf)]
+
+
+def distribution_async(problems: Sequence[Tuple[np.ndarray, np.ndarray]], n_frames: Sequence[int], s: float = 0.5):
+    """``distribution_many`` started NOW in the worker processes; returns ``wait() -> [P]``.  The caller enqueues GPU work
+    (the iteration's verification batch) between the two, so the fit runs beside the enqueue instead of after it.  Also for a
+    single problem (one search running alone: the fit is on its critical path).  Without a pool, or with more problems than
+    workers, ``wait`` runs ``distribution_many`` -- the same statements, the same P."""
+    global _pool_failed
+    nf = [int(n) for n in n_frames]
+    if len(nf) != len(problems) or any(n < 1 for n in nf):
+        raise ValueError("distribution_async: one positive n_frames per problem")
+    problems = [(np.array(x, dtype=np.float64), np.array(y, dtype=np.float64)) for x, y in problems]      # the caller's buffers may be reused
+    pool = get_pool() if problems else None
+    if pool is not None and len(problems) <= len(pool):
+        try:
+            count = pool.begin(problems, s, nf)
+        except (OSError, SplinePoolError) as e:
+            _pool_failed = True
+            print(f"tstar_amd: spline pool failed ({e}); fitting in-process", file=sys.stderr)
+        else:
+            def wait():
+                global _pool_failed
+                try:
+                    return pool.end(count)
+                except (OSError, SplinePoolError) as e:
+                    _pool_failed = True
+                    print(f"tstar_amd: spline pool failed ({e}); fitting in-process", file=sys.stderr)
+                    from .spline_worker import spline_distribution
+                    return [spline_distribution(x, y, n, s) for (x, y), n in zip(problems, nf)]
+            return wait
+    return lambda: distribution_many(problems, nf, s)
