@@ -451,8 +451,13 @@ def main():
         PL = max(1, args.pipeline)
         while PL > 1 and PL * L > 63:             # query-set slots of one detector handle (include/tstar_hip.h)
             PL -= 1
-        for i in range(0, len(items), L * PL):    # PL lock-step groups alternate on the GPU (tstar_amd.lockstep)
-            q.put((i, [items[j:j + L] for j in range(i, min(i + L * PL, len(items)), L)]))
+        # groups of at most L items, balanced (5 items at L = 4 -> 3 + 2, not 4 + 1); PL consecutive groups alternate on the
+        # GPU (tstar_amd.lockstep)
+        ng = (len(items) + L - 1) // L
+        sizes = [len(items) // ng + (1 if k < len(items) % ng else 0) for k in range(ng)] if ng else []
+        starts = [sum(sizes[:k]) for k in range(ng)]
+        for k in range(0, ng, PL):
+            q.put((starts[k], [items[starts[j]:starts[j] + sizes[j]] for j in range(k, min(k + PL, ng))]))
         out = [None] * len(items)
         errs = []
 
