@@ -49,7 +49,8 @@ QUESTIONS = [(["couch"], ["tv", "chair"]), (["dog"], ["leash", "park bench"]), (
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps = searched videos per rank; default 8 (two lock-step groups of 4), 48 with --heuristic yolo (two groups of 24)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=16, help="grid side g (g*g frames per iteration)")
     ap.add_argument("--max-batch", type=int, default=256, help="detector images per forward chunk")
@@ -75,7 +76,7 @@ def parse():
                          "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time; default 4 "
                          "with the OWL-ViT backend, 24 with YOLO-World (its grid forwards run at B = the group size: 57 TFLOP/s at 8, "
                          "72 at 16, 84 at 24, and an iteration's ~228 verification frames fill three full chunks of 76: 12.3 k frames/s "
-                         "against 12.05 k at 16 and 12.15 k at 31 in a same-box A/B; run it with --steps 48)")
+                         "against 12.05 k at 16 and 12.15 k at 31 in a same-box A/B; --steps defaults to 48 there)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="lock-step groups alternating on the GPU (tstar_amd.lockstep.search_lockstep_groups): while the detector runs "
                          "one group's verification batch the host does the other group's bookkeeping; one stream of detector work, "
@@ -103,6 +104,8 @@ def parse():
     args = ap.parse_args()
     if args.lockstep <= 0:
         args.lockstep = 24 if args.heuristic == "yolo" else 4
+    if args.steps is None:
+        args.steps = 48 if args.heuristic == "yolo" else 8
     return args
 
 
