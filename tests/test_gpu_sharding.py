@@ -166,3 +166,28 @@ def test_bench_two_ranks_equals_one_rank():
     assert one["config"]["gathered_keyframes"] == two["config"]["gathered_keyframes"]
     assert all(len(r) == 8 for r in one["config"]["gathered_keyframes"])
     assert "t0_boottime_ns" in one["config"]["timed_region"] and one["config"]["timed_region"]["t1_monotonic_ns"] > one["config"]["timed_region"]["t0_monotonic_ns"]
+
+
+def test_bench_line_contract():
+    """`python bench.py --steps K --warmup W` as the driver runs it at N = 1: exactly one JSON line on stdout with the
+    contract's keys, the roofline and cpu_baseline objects, self-consistent figures (value = frames / time, the time shares
+    below 1, achieved below the peak) and the keyframes of the timed region verified through the oracle."""
+    d = _bench_line([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-seconds", "3", "--no-grid4"],
+                    dict(os.environ))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "frames/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "frames scored/sec" in d["metric"] and "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    c, r, b = d["config"], d["roofline"], d["cpu_baseline"]
+    assert abs(d["ms_per_step"] * 1e-3 - c["sec_per_video"]) < 1e-9 and d["value"] > 1000
+    assert c["keyframes_verified"] is True and len(c["keyframes_rank0_step0"]) == 8 and c["lockstep_groups_alternating"] == 2
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "launches_timed", "launches_total",
+              "avg_launch_ms", "time_share_of_step"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and 0.5 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["launches_total"] >= r["launches_timed"] * (r["timed_every_nth_launch"] - 1) and r["launches_timed"] > 0
+    assert 0.5 < r["time_share_of_step"] + r["attention_f32_kernel"]["time_share_of_step"] < 1.0
+    assert b["kind"] == "port" and b["cores"] >= 1 and 1 < b["value"] < d["value"] and b["unit"] == "frames/s" and b["sample"]
