@@ -401,7 +401,11 @@ class TStarSearcher:
         if overlap is not None:
             from . import spline_pool
             wait = spline_pool.distribution_async([(vx, vy)], [self.total_frame_num])
-            ctx = overlap()
+            try:
+                ctx = overlap()
+            except BaseException:
+                wait()                      # the pool stays locked until its reply is collected
+                raise
             P = wait()[0]
         else:
             ctx = None
