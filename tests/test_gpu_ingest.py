@@ -26,7 +26,7 @@ def test_frames_to_grid_rgb(g):
     assert np.array_equal(grid.cpu().numpy(), R.frames_to_grid(list(synthetic_frames_numpy(secs, N, seed=4)), g, g))
 
 
-@pytest.mark.parametrize("ow,oh", [(600, 285), (800, 380), (640, 360), (37, 11)])
+@pytest.mark.parametrize("ow,oh", [(600, 285), (800, 380), (640, 360), (37, 11), (4, 3), (1, 5), (8, 2), (2, 1)])   # ow 4 / 1: one unit per row (magic_of(1))
 def test_frames_resize_rgb(ow, oh):
     from oracle import resize_ref as R
     from tstar_amd.video import synthetic_frames_numpy, synthetic_video

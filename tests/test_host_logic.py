@@ -159,6 +159,14 @@ res = run_sharded(10, None, world, rank, search_group=group, group_size=2)
 assert res == [search(i) for i in range(10)], res
 mine = shard_items(10, world, rank)
 assert seen == [mine[k:k + 2] for k in range(0, len(mine), 2)], seen
+# items that return ZERO keyframes keep their place (round-3 review: an all-(-1) row used to be dropped, shifting the rest
+# of that rank's items); item 1 (rank 1's first) and item 6 (rank 2's last) are empty, then every item is empty
+def search_some_empty(i):
+    return [] if i in (1, 6) else search(i)
+res = run_sharded(10, search_some_empty, world, rank)
+assert res == [search_some_empty(i) for i in range(10)], res
+res = run_sharded(10, lambda i: [], world, rank)
+assert res == [[] for _ in range(10)], res
 from tstar_amd import sharding
 assert "gloo" in sharding.LAST_GATHER_PATH and "4 ranks" in sharding.LAST_GATHER_PATH
 dist.destroy_process_group()
@@ -463,6 +471,13 @@ def test_compressed_sequence_front_end(tmp_path):
     st = V.open_video(p, device="cpu")
     assert st.raw_fps == 3.5 and st.num_seconds == 4
     assert all(np.array_equal(st.frames.numpy()[s], frames[int(s * 3.5)]) for s in range(4))
+    # slower than 1 fps: 5 frames of 2000 ms = 10 s at 0.5 fps -> every raw frame serves two logical seconds
+    for ext, kw in ((".gif", {}), (".webp", dict(lossless=True))):
+        p = str(tmp_path / ("slow" + ext))
+        pil[0].save(p, save_all=True, append_images=pil[1:5], duration=2000, loop=0, **kw)
+        st = V.load_pillow_sequence(p, device="cpu", chunk=3)          # chunk 3: a frame's two seconds straddle a copy
+        assert st.raw_fps == 0.5 and st.num_seconds == 10 and st.raw_total_frames == 5, ext
+        assert all(np.array_equal(st.frames.numpy()[s], frames[s // 2]) for s in range(10)), ext
     # a single still image is not a video; a missing file reads like the reference's error
     pil[0].save(str(tmp_path / "still.png"))
     with pytest.raises(ValueError, match="Cannot open video file"):

@@ -665,9 +665,10 @@ __global__ __launch_bounds__(256) void bilinear_gather_nv12_kernel(const uint8_t
 // TSTAR_INGEST_GENERIC=1 forces the generic kernels on RGB sources too (before / after counter runs, tools/pmc_ingest_counters.sh)
 static bool rgb_fast_ok(int W, long long npix, int div) {
     static const bool generic = [] { const char* e = getenv("TSTAR_INGEST_GENERIC"); return e && atoi(e) != 0; }();
-    return !generic && W >= 3 && npix > 0 && npix * (long long)div < (1ll << 32) && npix < (1ll << 31);
+    // div >= 2: magic_of(1) would be 2^32, which does not fit the 32-bit multiplier (the row / column split would read past the tap tables)
+    return !generic && W >= 3 && div >= 2 && npix > 0 && npix * (long long)div < (1ll << 32) && npix < (1ll << 31);
 }
-static unsigned magic_of(int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+static unsigned magic_of(int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }   // d >= 2 (rgb_fast_ok)
 
 // one bilinear sample (all three channels) at output taps tx, ty
 template <class SRC>
@@ -714,7 +715,7 @@ int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int
         rc = get_fused(0, W, 0, ow, 3 * W, &fx); if (rc) return rc;
         rc = get_fused(1, H, 0, oh, 3 * W, &fy); if (rc) return rc;
         // 4 pixels per lane need dword-aligned 12-byte stores: a row of the output must be a multiple of 4 pixels
-        const int px = (ow % 4 == 0 && (reinterpret_cast<size_t>(out) & 3) == 0) ? 4 : 1;
+        const int px = (ow % 4 == 0 && ow >= 8 && (reinterpret_cast<size_t>(out) & 3) == 0) ? 4 : 1;   // ow / px >= 2 (magic_of)
         const int owq = ow / px, nunits = owq * oh;
         const dim3 g((unsigned)((nunits + 255) / 256), (unsigned)n);
         if (px == 4) hipLaunchKernelGGL(bilinear_gather_rgb_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
@@ -726,7 +727,7 @@ int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int
         const uint4 *fx, *fy;
         rc = get_fused_nv12(6, W, 0, ow, W, H, &fx); if (rc) return rc;
         rc = get_fused_nv12(7, H, 0, oh, W, H, &fy); if (rc) return rc;
-        const int px = (ow % 4 == 0 && (reinterpret_cast<size_t>(out) & 3) == 0) ? 4 : 1;
+        const int px = (ow % 4 == 0 && ow >= 8 && (reinterpret_cast<size_t>(out) & 3) == 0) ? 4 : 1;   // ow / px >= 2 (magic_of)
         const int owq = ow / px, nunits = owq * oh;
         const dim3 g((unsigned)((nunits + 255) / 256), (unsigned)n);
         if (px == 4) hipLaunchKernelGGL(bilinear_gather_nv12_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3 / 2, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
@@ -787,7 +788,7 @@ int frames_to_grid_u8(const uint8_t* video, int H, int W, const int* d_idx, int 
         // one pixel per lane here: four (12-byte stores) measured 63 us against 52 for the 256-frame grid -- 32 window loads
         // and five dependent mix levels per lane leave too few lanes in flight; the grid's stores are 8 % of its bytes anyway
         static const int px_env = [] { const char* e = getenv("TSTAR_GRID_PX"); return e ? atoi(e) : 1; }();
-        const int px = (px_env == 4 && cw % 4 == 0 && (reinterpret_cast<size_t>(grid) & 3) == 0) ? 4 : 1;
+        const int px = (px_env == 4 && cw % 4 == 0 && cw >= 8 && (reinterpret_cast<size_t>(grid) & 3) == 0) ? 4 : 1;
         const int cwq = cw / px;
         const dim3 g((unsigned)((cwq * ch + 255) / 256), (unsigned)(rows * cols));
         if (px == 4) hipLaunchKernelGGL(frames_to_grid_rgb_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, cols, cw, ch, cwq, magic_of(cwq), fx, fy, grid);

@@ -106,29 +106,38 @@ def gather_keyframes(local_rows: Sequence[Sequence[int]], world: int, pad_to: in
     nrow, k = int(shape[0]), int(shape[1])
     if pad_to is not None:
         nrow = max(nrow, pad_to)
-    host = torch.full((nrow, k), -1, dtype=torch.int32)
+    # wire format per rank: [row count, nrow * k indices padded with -1].  The explicit count keeps an item that found
+    # ZERO keyframes in its place (an all-(-1) row) instead of shifting every later item of that rank.
+    host = torch.full((1 + nrow * k,), -1, dtype=torch.int32)
+    host[0] = len(rows)
     for i, r in enumerate(rows):
-        host[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+        if r:
+            host[1 + i * k:1 + i * k + len(r)] = torch.tensor(r, dtype=torch.int32)
     buf = host.to(dev)
-    comm = _tstar_comm(world, dist.get_rank()) if on_gpu and nrow * k > 0 else None
+    n_i32 = 1 + nrow * k
+    comm = _tstar_comm(world, dist.get_rank()) if on_gpu else None
     if comm is not None:                         # the C-ABI entry a non-Python host would call: ncclAllGather on our stream
         from . import _lib
-        flat = torch.empty((world, nrow, k), dtype=torch.int32, device=dev)
-        _lib.check(_lib.load().tstar_allgather_i32(comm, buf.data_ptr(), flat.data_ptr(), nrow * k, _lib.stream_ptr()),
+        flat = torch.empty((world, n_i32), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().tstar_allgather_i32(comm, buf.data_ptr(), flat.data_ptr(), n_i32, _lib.stream_ptr()),
                    "tstar_allgather_i32")
         out = list(flat.cpu())                   # synchronises the stream
         LAST_GATHER_PATH = (f"tstar_allgather_i32: ncclAllGather on the library's own RCCL communicator "
-                            f"({world} ranks, {nrow * k} int32 per rank, the caller's stream)")
+                            f"({world} ranks, {n_i32} int32 per rank, the caller's stream)")
     else:
         out = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(out, buf)
         LAST_GATHER_PATH = (f"torch.distributed.all_gather over {dist.get_backend()} ({world} ranks)"
-                            + ("; the library's RCCL communicator was unavailable" if on_gpu and nrow * k > 0 else ""))
+                            + ("; the library's RCCL communicator was unavailable" if on_gpu else ""))
     res: List[List[int]] = []
     for t in out:
-        for row in t.cpu().numpy():
-            if (row >= 0).any():
-                res.append([int(v) for v in row if v >= 0])
+        flat_r = t.cpu().numpy()
+        cnt = int(flat_r[0])
+        if cnt < 0 or cnt > nrow:
+            raise RuntimeError(f"gather_keyframes: a rank reported {cnt} rows of at most {nrow}")
+        body = flat_r[1:].reshape(nrow, k) if k else None
+        for i in range(cnt):
+            res.append([int(v) for v in body[i] if v >= 0] if k else [])
     return res
 
 

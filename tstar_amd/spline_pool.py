@@ -118,7 +118,7 @@ class SplinePool:
                         self._send(p, x, y, s, nf[lo + j])
                     for j, p in enumerate(self._procs[:len(chunk)]):
                         out[lo + j] = self._recv(p)
-            except (OSError, SplinePoolError):
+            except BaseException:
                 self.close()                    # a half-served pool cannot be resynchronised
                 raise
         return out
@@ -144,8 +144,8 @@ class SplinePool:
         """The replies of the ``begin`` before, in input order."""
         try:
             return [self._recv(p) for p in self._procs[:count]]
-        except (OSError, SplinePoolError):
-            self.close()
+        except BaseException:                   # incl. KeyboardInterrupt / MemoryError: unread replies must never be
+            self.close()                        # taken for the next call's
             raise
         finally:
             self._lock.release()

@@ -297,8 +297,9 @@ def load_pillow_sequence(path: str, device: str = "cuda", chunk: int = 64) -> Fr
             return np.asarray(im.convert("RGB"), dtype=np.uint8), float(im.info.get("duration", 0) or 0)
 
         def wanted(fps):
+            """Raw frame of every logical second (non-decreasing; a stream slower than 1 fps names a frame repeatedly)."""
             n_sec = int(n / fps)
-            return n_sec, {int(sec * fps): sec for sec in range(n_sec)}
+            return n_sec, [int(sec * fps) for sec in range(n_sec)]
 
         # One decode pass under the hypothesis that every frame lasts as long as the first (the usual case); the pass also
         # collects the real durations, and only a stream with varying durations is decoded a second time at its true rate.
@@ -312,16 +313,19 @@ def load_pillow_sequence(path: str, device: str = "cuda", chunk: int = 64) -> Fr
                 raise ValueError(f"Cannot open video file: {path} (shorter than one second)")
             store = torch.empty((n_sec, h, w, 3), dtype=torch.uint8, device=device)
             host = np.empty((min(chunk, n_sec), h, w, 3), dtype=np.uint8)
-            total_ms, filled, base = 0.0, 0, 0
+            total_ms, filled, base, sec = 0.0, 0, 0, 0
             for i in range(n):
                 fr, d = (f0, d0) if i == 0 else frame(i)
                 total_ms += d
-                if i in want:                               # raw indices grow with the second, so seconds arrive in order
+                while sec < n_sec and want[sec] == i:       # every second that maps to raw frame i, in order
                     host[filled] = fr
                     filled += 1
-                    if filled == len(host) or want[i] == n_sec - 1:
+                    sec += 1
+                    if filled == len(host) or sec == n_sec:
                         store[base:base + filled].copy_(torch.from_numpy(host[:filled]))
                         base, filled = base + filled, 0
+            if base != n_sec:
+                raise ValueError(f"Cannot open video file: {path} (decoded {base} of {n_sec} seconds)")
             true_fps = n * 1000.0 / total_ms
             if abs(true_fps - fps) <= 1e-9 * fps:
                 break
@@ -377,14 +381,17 @@ def open_video(video, device: str = "cuda") -> FrameStore:
         raise ValueError(f"Cannot open video file: {video}")
     fps = cap.get(cv2.CAP_PROP_FPS)
     total = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
-    want = {int(sec * fps) for sec in range(int(total / fps))}
-    out, i = [], 0
-    while True:
+    want = [int(sec * fps) for sec in range(int(total / fps))]
+    out, i, sec = [], 0, 0
+    while sec < len(want):
         ok, fr = cap.read()
         if not ok:
             break
-        if i in want:
-            out.append(torch.from_numpy(fr[:, :, ::-1].copy()).to(device))
+        if want[sec] == i:
+            dev = torch.from_numpy(fr[:, :, ::-1].copy()).to(device)
+            while sec < len(want) and want[sec] == i:       # a stream slower than 1 fps names a frame repeatedly
+                out.append(dev)
+                sec += 1
         i += 1
     cap.release()
     return FrameStore(torch.stack(out), fps, total, name=video)
