@@ -62,11 +62,12 @@ def parse():
                          "in lock-step an iteration verifies about 228 frames = three chunks of 76 (+ a small remainder)")
     ap.add_argument("--nframes", type=int, default=N_FRAMES)
     ap.add_argument("--search-nframes", type=int, default=8)
-    ap.add_argument("--weights", choices=["f32", "bf16", "bf16_exact", "f32_split"], default="f32",
+    ap.add_argument("--weights", choices=["f32", "bf16", "bf16_exact", "f32x3"], default="f32",
                     help="bf16 = BASELINE config 5 (bf16-rounded weights on the bf16 matrix pipe, f32 activations as two bf16 terms: "
                          "2 MFMA products per algorithmic product); with --nframes 14400 --grid 15 --search-nframes 32 this is "
                          "configs[4].  bf16_exact = the same weights with the activations split exactly into three terms (3 products). "
-                         "f32_split = fp32 checkpoint with every operand carried as two bf16 terms (opt-in, no longer maintained)")
+                         "f32x3 = fp32 checkpoint on the bf16 matrix pipe with every operand carried as THREE exact bf16 terms (all 24 bits), "
+                         "six partial products, f32 accumulation (opt-in; GEMM error vs float64 no larger than the f32 MFMA tile's)")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="independent searches in flight per GPU (host threads, one HIP stream + one scorer "
                          "workspace each); 2 fills kernel tails and gives ~+5 %% throughput, but overlapping "
@@ -99,6 +100,11 @@ def parse():
     ap.add_argument("--no-grid4", action="store_true",
                     help="skip the config.grid4 sub-record (the reference's DEFAULT 4x4 grid, where 'sec/video' is what a user of "
                          "the reference sees: one solo search and 16 videos in lock-step, untimed by the driver)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip config.other_configs: after the timed region of the DEFAULT line (N = 1, OWL-ViT, f32, configs[1]) bench.py runs "
+                         "itself three more times -- configs[3] (YOLO-World, 48 steps), configs[4] (bf16 weights, 14400 frames, K = 32, grid 15) "
+                         "and the f32x3 mode on configs[1] -- and embeds value / roofline / keyframes_verified of each, so that the driver "
+                         "observes them too (about +70 s, none of it inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
@@ -355,6 +361,36 @@ def cpu_baseline_yolo(args, stats):
             "sec_per_video": per_video}
 
 
+def other_configs():
+    """BASELINE configs[3], configs[4] and the f32x3 mode, each as its own bench.py process AFTER this line's timed region
+    (fresh process = its own warm-up, barriers and timed region; nothing shared with the headline).  Summaries only."""
+    import subprocess
+    runs = {
+        "configs[3] yolo": ["--heuristic", "yolo", "--steps", "48"],
+        "configs[4] bf16 weights, 14400 frames, K=32, grid 15": ["--weights", "bf16", "--nframes", "14400", "--grid", "15", "--search-nframes", "32", "--steps", "8"],
+        "configs[1] in the f32x3 mode": ["--weights", "f32x3", "--steps", "8"],
+    }
+    out = {}
+    for name, flags in runs.items():
+        t1 = time.perf_counter()
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--warmup", "1", "--no-cpu-baseline", "--no-grid4", "--no-other-configs"] + flags
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}
+                continue
+            j = json.loads(line[-1])
+            out[name] = {"value": j["value"], "unit": j["unit"], "steps": j["steps"], "ms_per_step": j["ms_per_step"], "dtype": j["dtype"],
+                         "sec_per_video": j["config"]["sec_per_video"], "single_search_alone_latency_sec": j["config"]["single_search_alone_latency_sec"],
+                         "keyframes_verified": j["config"]["keyframes_verified"], "host_cpu_sec_per_video": j["config"]["host_cpu_sec_per_video"],
+                         "roofline": {k: j["roofline"].get(k) for k in ("kernel", "bound", "achieved", "achieved_algorithmic", "peak", "unit", "frac", "time_share_of_step")},
+                         "workload": j["config"]["workload"], "command": "python bench.py " + " ".join(cmd[2:]), "wall_s": time.perf_counter() - t1}
+        except Exception as e:                                  # a sub-run must never take the headline line down
+            out[name] = {"error": repr(e)}
+    return out
+
+
 def main():
     args = parse()
     # the searcher prints progress like the reference ("Found target ...", sampler warnings): keep stdout
@@ -524,7 +560,15 @@ def main():
         return {f"t{which}_realtime_ns": time.time_ns(), f"t{which}_monotonic_ns": time.monotonic_ns(),
                 f"t{which}_boottime_ns": time.clock_gettime_ns(time.CLOCK_BOOTTIME)}
 
+    from tstar_amd import spline_pool as _sp
+
+    def host_cpu_seconds():
+        """user + system CPU seconds consumed so far by this rank's process (all threads) and by its FITPACK worker processes."""
+        pool = _sp._pool
+        return time.process_time() + (pool.cpu_seconds() if pool is not None else 0.0)
+
     timed_region = stamp(0)
+    cpu0 = host_cpu_seconds()
     t0 = time.perf_counter()
     res = run_many(items)
     frames = sum(r[0].frames_scored for r in res)
@@ -543,6 +587,7 @@ def main():
     timed_region.update(stamp(1))
     barrier()
     dt = time.perf_counter() - t0
+    host_cpu = host_cpu_seconds() - cpu0
     t = torch.tensor([dt, float(frames), float(images)], dtype=torch.float64, device=cdev)
     if world > 1:
         tmax = t.clone()
@@ -574,7 +619,7 @@ def main():
     # timed process, so the per-launch figure measured with `tools/rocpd_traffic.py` is read from the
     # committed summary (profiles/); None if it has not been collected.
     traffic, traffic_src = None, None
-    for tag in ("r03", "r02", "r01"):              # the newest collection (tools/collect_profiles.sh) wins
+    for tag in ("r04", "r03", "r02", "r01"):       # the newest collection (tools/collect_profiles.sh) wins
         tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_gemm_traffic.json")
         if os.path.isfile(tp):
             try:
@@ -590,7 +635,7 @@ def main():
     if args.heuristic == "yolo":
         gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel + conv_sw_kernel (implicit-GEMM convolutions, v_pk_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
         traffic, traffic_src = None, None
-        for tag in ("r03", "r02"):                # tools/collect_yolo_profiles.sh (PMC passes of this command)
+        for tag in ("r04", "r03", "r02"):         # tools/collect_yolo_profiles.sh (PMC passes of this command)
             tp = os.path.join(ROOT, "profiles", f"{tag}_yolo_pmc_conv_traffic.json")
             if os.path.isfile(tp):
                 try:
@@ -600,8 +645,11 @@ def main():
                     pass
     elif args.weights == "bf16":
         gemm_kernel, peak, exec_mult = "gemm_bf16w2_wide_kernel / gemm_f32_kernel<WMODE=3> (2 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 2.0
-    elif args.weights in ("bf16_exact", "f32_split"):
-        gemm_kernel, peak, exec_mult = f"gemm_f32_kernel<WMODE={1 if args.weights == 'bf16_exact' else 2}> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
+    elif args.weights == "bf16_exact":
+        gemm_kernel, peak, exec_mult = "gemm_f32_kernel<WMODE=1> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
+    elif args.weights == "f32x3":
+        gemm_kernel, peak, exec_mult = ("gemm_bf16w2_wide_kernel<WMODE=4> / gemm_f32_kernel<WMODE=4> (gemm_tile_x3: 6 x v_mfma_f32_32x32x16_bf16 per K=16, "
+                                        "weight planes global -> VGPR in fragment order)"), BF16_MFMA_PEAK_TFLOPS, 6.0
     else:
         gemm_kernel, peak, exec_mult = "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1.0
     # post-run parity check of the keyframes this run produced (rank 0, step 0): solo re-run + oracle replay, untimed
@@ -632,7 +680,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": "f32 activations (two round-to-nearest bf16 terms) x bf16 weights, exact products, f32 accumulate",
                       "bf16_exact": "f32 activations x bf16 weights (exact 3-term split on the bf16 MFMA pipe)",
-                      "f32_split": "f32 operands as 2 bf16 terms each (16 significand bits), 3 bf16 MFMA products, f32 accumulate"}[args.weights],
+                      "f32x3": "f32: GEMM operands as 3 exact bf16 terms each (all 24 significand bits), 6 of the 9 partial products (ka + kw <= 2; "
+                               "each exact), f32 accumulate -- GEMM error vs float64 <= the native f32 MFMA tile's (tests); attention / LayerNorm native f32"}[args.weights],
             "data": "synthetic",
             "config": {
                 "collective_backend": (backend if world > 1 else None), "collective_path": collective_path,
@@ -642,6 +691,13 @@ def main():
                 "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc, "lockstep_items_per_batch": max(1, min(args.lockstep, 31)),
                 "lockstep_groups_alternating": max(1, args.pipeline),
                 "mean_search_latency_sec": latency, "single_search_alone_latency_sec": solo_latency,
+                # what predicts the 8-rank curve: CPU seconds (user + sys) of this rank's process AND its spline worker processes over
+                # the timed region, per video; host_cores = hardware threads this process may run on (its affinity mask)
+                "host_cpu_sec_per_video": host_cpu / max(args.steps, 1), "host_cpu_busy_cores": host_cpu / dt,
+                "host_cores": _sp.host_threads(), "host_spline_workers": (len(_sp._pool) if _sp._pool is not None else 0),
+                # the per-iteration annotated grid images / frames the reference keeps unconditionally (interface_searcher.py:469-474)
+                # are NOT produced in the timed region (keep_visual_history=False); with them a search costs +2-4 %
+                "visual_history": False,
                 "grid_calls_per_video": grid_calls / args.steps, "verify_calls_per_video": verify_calls / args.steps,
                 "detector_images_per_video": images / args.steps, "max_batch": args.yolo_max_batch if args.heuristic == "yolo" else args.max_batch,
                 "keyframes_rank0_step0": keys[0], "gathered_keyframe_rows": len(all_keys), "gathered_keyframes": all_keys,
@@ -676,6 +732,9 @@ def main():
         if world == 1 and not args.no_grid4 and args.heuristic == "owl" and workload == "single" and g != 4:
             g4rec = grid4_record(heuristics[0], shared_store, args.nframes, args.search_nframes)
             out["config"]["grid4"] = g4rec
+        if (world == 1 and not args.no_other_configs and args.heuristic == "owl" and args.weights == "f32" and workload == "single"
+                and args.nframes == N_FRAMES and g == 16 and args.search_nframes == 8):
+            out["config"]["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             stats_ = {"grid_calls": grid_calls / args.steps, "verify_calls": verify_calls / args.steps, "grid4": g4rec}
             out["cpu_baseline"] = cpu_baseline_yolo(args, stats_) if args.heuristic == "yolo" else cpu_baseline(args, stats_)

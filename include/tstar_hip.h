@@ -66,20 +66,27 @@ typedef struct tstar_owl tstar_owl;
  *     round-to-nearest bf16 terms a_hi + a_lo (16 significand bits, |a - a_hi - a_lo| <= 2^-17 |a|):
  *     C += a_lo*w + a_hi*w, exact products, f32 accumulation -- 2 MFMA products per algorithmic product.
  *     Detector scores stay within 1e-3 of a float32 run on the same rounded weights (tests state the measured
- *     bound, ~1e-5).  The vision tower's attention runs on the bf16 pipe as well in modes 1-3 (f32-split
+ *     bound, ~1e-5).  The vision tower's attention runs on the bf16 pipe as well in modes 1 and 3 (f32-split
  *     operands: two bf16 terms each, 3 products, f32 accumulation).
- *   TSTAR_WEIGHTS_F32_SPLIT (2): float32 checkpoints on the bf16 matrix pipe: each weight is kept as two
- *     bfloat16 terms hi + lo and each activation is split into two terms on the fly (round to nearest,
- *     16 significand bits per operand); C += a_lo*w_hi + a_hi*w_lo + a_hi*w_hi with exact products and f32
- *     accumulation (the 2^-18 a_lo*w_lo term is dropped).  Detector scores stay within 1e-3 of the
- *     float32 path (tests state the measured bound); opt-in, never the default.
+ *   (2, TSTAR_WEIGHTS_F32_SPLIT of ABI 2 -- both operands as two bf16 terms, 16 significand bits -- is retired and
+ *     refused; TSTAR_WEIGHTS_F32X3 below carries all 24 bits.)
  *   TSTAR_WEIGHTS_BF16_EXACT (3): bf16 weights with the activations split EXACTLY into three bf16 terms
  *     (8 + 8 + 8 significand bits, truncation split; 3 MFMA products): the f32-accumulated product of the f32
- *     activations with the bf16 weights, f32-roundoff class (round 1-2's bf16 mode, kept selectable). */
+ *     activations with the bf16 weights, f32-roundoff class (round 1-2's bf16 mode, kept selectable).
+ *   TSTAR_WEIGHTS_F32X3 (4) (ABI 3): float32 checkpoints on the bf16 matrix pipe WITHOUT dropping an operand bit: every
+ *     weight and every activation is split exactly into three round-to-nearest bfloat16 terms (8 + 8 + 8 significand
+ *     bits, signed remainders; weights once at creation, packed in MFMA-fragment order, 6 bytes per weight) and
+ *     C += a0 w2 + a1 w1 + a0 w1 + a2 w0 + a1 w0 + a0 w0 per K = 16 step -- the six partial products with ka + kw <= 2,
+ *     each exact, f32 accumulation.  The three products left out are <= 2^-24 |a w| each and zero-mean; measured
+ *     against float64 the result is no further away than the exact-f32 MFMA tile's (tests assert it on every shape
+ *     they run; the nine-product form has the same error to four digits).  1.3-1.45x the f32 tile's rate on the batch
+ *     shapes.  Attention, LayerNorm and the heads' tails stay float32.  Opt-in; the headline is quoted in mode 0.
+ * ABI note (tstar_abi_version() == 3): since ABI 2 mode 1 means TWO-term activations (it was the exact three-term split,
+ * now mode 3), TSTAR_OWL_MAX_SETS went 32 -> 64, mode 2 was retired and mode 4 added. */
 #define TSTAR_WEIGHTS_F32 0
 #define TSTAR_WEIGHTS_BF16 1
-#define TSTAR_WEIGHTS_F32_SPLIT 2
 #define TSTAR_WEIGHTS_BF16_EXACT 3
+#define TSTAR_WEIGHTS_F32X3 4
 int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_vision,
                      const float* h_text_blob, size_t n_text, const float* h_norm_lut, int max_batch,
                      int weights_mode);
@@ -299,9 +306,10 @@ int tstar_gemm_bf16w2(const float* d_A, const float* d_W, float* d_C, const floa
  * (microbenchmarks) */
 int tstar_gemm_bf16w_pre(const float* d_A, const void* d_Wb, float* d_C, const float* d_bias, const float* d_residual,
                          int M, int N, int K, int act, int a_terms, int tile_cfg, void* stream);
-/* f32-split GEMM (diagnostic): W is split into two bfloat16 terms on the device, A into two on the fly; synchronises */
-int tstar_gemm_f32_split(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
-                         int M, int N, int K, int act, int tile_cfg, void* stream);
+/* f32x3 GEMM (diagnostic): W is packed into three exact bf16 planes on the device, A is split on the fly, six products
+ * (TSTAR_WEIGHTS_F32X3); N % 128 == 0, K % 32 == 0; tile_cfg as above, 4 forces the 128x256 tile, 5 forbids it; synchronises */
+int tstar_gemm_f32x3(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
+                     int M, int N, int K, int act, int tile_cfg, void* stream);
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream);
 /* qkv [B*T, 3*heads*64] -> out [B*T, heads*64]; mode 0 full, 1 causal + key mask u8 [B,T] */
 int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode,

@@ -787,34 +787,38 @@ def test_reference_style_manual_loop_equals_search():
     assert sorted(a.remaining_targets) == sorted(b.remaining_targets)
 
 
-def test_f32_split_mode_search_tracks_the_f32_search():
-    """The opt-in f32_split mode (GEMMs and the vision attention on the bf16 matrix pipe, 16 significand bits per
-    operand) through a whole search: every detector score the searcher consumed must agree with the exact-f32 mode on
-    the SAME images within the 1e-3 contract (observed ~1e-6); with identical confidences up to that level the two
-    searches visit the same frames here and return the same keyframes (reported, and asserted for this seeded case)."""
+def test_f32x3_mode_search_teacher_forced_and_against_f32():
+    """The opt-in f32x3 mode through a whole search: (a) teacher-forced -- the confidences it produced, replayed through the
+    oracle searcher, give the same sampled seconds and keyframes bit for bit; (b) every detector score the searcher consumed
+    agrees with the exact-f32 mode on the SAME images within 1e-5 (contract 1e-3); (c) the two closed-loop searches visit the
+    same frames here and return the same keyframes (reported, and asserted for this seeded case)."""
     from tstar_amd.interface_heuristic import OWLInterface
     from tstar_amd.interface_searcher import TStarSearcher
     from tstar_amd.video import synthetic_video
     import torch
-    store = synthetic_video(900, seed=6)
+    N, g, K, seed = 900, 6, 6, 11
+    store = synthetic_video(N, seed=6)
     runs = {}
-    for mode in ("f32", "f32_split"):
+    for mode in ("f32", "f32x3"):
         h = OWLInterface(synthetic_seed=0, max_batch=32, weights_dtype=mode)
         rec = _Recorder(h)
-        s = TStarSearcher(store, h, ["couch"], ["tv", "chair"], search_nframes=6, image_grid_shape=(6, 6),
-                          search_budget=0.3, confidence_threshold=0.6, rng=np.random.RandomState(11),
+        s = TStarSearcher(store, h, ["couch"], ["tv", "chair"], search_nframes=K, image_grid_shape=(g, g),
+                          search_budget=0.3, confidence_threshold=0.6, rng=np.random.RandomState(seed),
                           keep_visual_history=False)
+        log = []
+        orig = s.sample_frames
+        s.sample_frames = (lambda o, lg: lambda num: (lambda r: (lg.append(list(r[0])), r)[1])(o(num)))(orig, log)
         _, ts = s.search()
-        runs[mode] = (h, rec, list(ts), s.iterations)
-    h32, rec32, ts32, it32 = runs["f32"]
-    hs, recs, tss, its = runs["f32_split"]
-    # re-score every image the split run consumed with the exact-f32 scorer
+        runs[mode] = (h, rec, list(ts), s.iterations, log)
+    h32, rec32, ts32, it32, _ = runs["f32"]
+    hs, recs, tss, its, logs = runs["f32x3"]
+    ref, ts_ref = _replay_through_oracle(recs, hs, ["couch"], ["tv", "chair"], N, g, K, 0.3, 0.6, seed)
+    assert [it["secs"] for it in ref.trace] == logs and ts_ref == [float(t) for t in tss]
     worst = 0.0
     for c in recs.calls:
         r = rec32._orig(torch.from_numpy(c["images"]).cuda(), c["rows"], c["cols"])
         worst = max(worst, float(np.abs(r.scores.cpu().numpy() - c["scores"]).max()))
-    print(f"f32_split search: {its} iterations, {len(recs.calls)} detector batches, max |score - f32 score| = {worst:.2e}; "
+    print(f"f32x3 search: {its} iterations, {len(recs.calls)} detector batches, max |score - f32 score| = {worst:.2e}; "
           f"keyframes {'equal' if tss == ts32 else 'differ'}")
-    assert worst < 1e-3
-    assert worst < 1e-4
+    assert worst < 1e-5
     assert its == it32 and tss == ts32

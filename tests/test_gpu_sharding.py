@@ -191,3 +191,17 @@ def test_bench_line_contract():
     assert r["launches_total"] >= r["launches_timed"] * (r["timed_every_nth_launch"] - 1) and r["launches_timed"] > 0
     assert 0.5 < r["time_share_of_step"] + r["attention_f32_kernel"]["time_share_of_step"] < 1.0
     assert b["kind"] == "port" and b["cores"] >= 1 and 1 < b["value"] < d["value"] and b["unit"] == "frames/s" and b["sample"]
+    # round 4: the host budget of a rank (what predicts the 8-rank curve), the visual-history statement, and the other BASELINE
+    # configs observed through the same line
+    assert c["visual_history"] is False and c["host_cores"] >= 1 and 0 < c["host_cpu_sec_per_video"] < 60 and c["host_cpu_busy_cores"] > 0
+    oc = c["other_configs"]
+    assert len(oc) == 3
+    for name, rec in oc.items():
+        assert "error" not in rec, (name, rec)
+        assert rec["keyframes_verified"] is True and rec["value"] > 1000 and 0 < rec["roofline"]["frac"] < 1, (name, rec)
+    y = [v for k, v in oc.items() if "configs[3]" in k][0]
+    assert y["roofline"]["bound"] == "valu" and "configs[3]" in y["workload"]
+    c5 = [v for k, v in oc.items() if "configs[4]" in k][0]
+    assert "14400-frame" in c5["workload"] and "search_nframes=32" in c5["workload"] and "bf16" in c5["dtype"]
+    x3 = [v for k, v in oc.items() if "f32x3" in k][0]
+    assert "3 exact bf16 terms" in x3["dtype"] and x3["roofline"]["peak"] == 2500.0

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.tstar_abi_version() == 2
+    assert lib.tstar_abi_version() == 3
 
 
 def test_blob_layout_matches_library():

@@ -102,18 +102,19 @@ struct tstar_owl {
     int seq_cap = TSTAR_OWL_MAX_QUERIES;                             // sequences the three staging buffers above hold
     std::map<int, ResampleTable> tabs;   // in_size -> table to 768
     // weights_mode 1 / 3 (BASELINE config 5, bf16 weights; two-term / exact three-term activations): bfloat16 copy of every
-    // GEMM weight matrix; weights_mode 2 (f32 split): two bfloat16 terms hi + lo per matrix (16 significand bits)
+    // GEMM weight matrix; weights_mode 4 (f32x3): every f32 matrix as three exact bf16 planes in MFMA-fragment order
     int weights_mode = TSTAR_WEIGHTS_F32;
-    std::unordered_map<const float*, __bf16*> wb, wb_lo;
+    std::unordered_map<const float*, __bf16*> wb;
+    std::unordered_map<const float*, void*> wp;
     const __bf16* bf16_of(const float* w) const {
-        if (weights_mode == TSTAR_WEIGHTS_F32) return nullptr;
+        if (weights_mode != TSTAR_WEIGHTS_BF16 && weights_mode != TSTAR_WEIGHTS_BF16_EXACT) return nullptr;
         auto it = wb.find(w);
         return it == wb.end() ? nullptr : it->second;
     }
-    const __bf16* bf16_lo_of(const float* w) const {
-        if (weights_mode != TSTAR_WEIGHTS_F32_SPLIT) return nullptr;
-        auto it = wb_lo.find(w);
-        return it == wb_lo.end() ? nullptr : it->second;
+    const void* packed_of(const float* w) const {
+        if (weights_mode != TSTAR_WEIGHTS_F32X3) return nullptr;
+        auto it = wp.find(w);
+        return it == wp.end() ? nullptr : it->second;
     }
 };
 
@@ -171,7 +172,7 @@ static int get_table(tstar_owl* h, int in_size, ResampleTable** out, hipStream_t
 static GemmArgs mk_gemm(const tstar_owl* h, const float* A, const float* W, float* C, const float* bias, const float* res,
                         int M, int N, int K, int lda, int ldc, int act) {
     GemmArgs g{};
-    g.A = A; g.W = W; g.Wb = h ? h->bf16_of(W) : nullptr; g.Wb2 = h ? h->bf16_lo_of(W) : nullptr; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
+    g.A = A; g.W = W; g.Wb = h ? h->bf16_of(W) : nullptr; g.Wp = h ? h->packed_of(W) : nullptr; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0; g.tile_cfg = -1; g.m_split = 0;
     g.a_terms = h && h->weights_mode == TSTAR_WEIGHTS_BF16 ? 2 : 0;      // bf16 weights: two-term activations unless the exact mode is asked for
     return g;
@@ -185,8 +186,9 @@ static int run_encoder(tstar_owl* h, const LayerW* layers, int nlayers, int B, i
         const LayerW& w = layers[l];
         RC(layernorm_f32(h->x, h->xn, w.ln1_w, w.ln1_b, M, D, s));
         RC(gemm_f32(mk_gemm(h, h->xn, w.qkv_w, h->qkv, w.qkv_b, nullptr, M, 3 * D, D, D, 3 * D, ACT_NONE), s));
-        // full attention in the opt-in bf16-pipe modes runs on the bf16 matrix pipe too (f32-split operands)
-        if (mode == 0 && h->weights_mode != TSTAR_WEIGHTS_F32) RC(attention_split(h->qkv, h->att, B, T, heads, s));
+        // full attention in the bf16-WEIGHT modes runs on the bf16 matrix pipe too (operands as two bf16 terms); the f32x3
+        // mode keeps the exact-f32 attention: its claim is an error no larger than the f32 path's
+        if (mode == 0 && (h->weights_mode == TSTAR_WEIGHTS_BF16 || h->weights_mode == TSTAR_WEIGHTS_BF16_EXACT)) RC(attention_split(h->qkv, h->att, B, T, heads, s));
         else RC(attention_f32(h->qkv, h->att, B, T, heads, mode, key_mask, s));
         RC(gemm_f32(mk_gemm(h, h->att, w.out_w, h->x, w.out_b, h->x, M, D, D, D, D, ACT_NONE), s));
         RC(layernorm_f32(h->x, h->xn, w.ln2_w, w.ln2_b, M, D, s));
@@ -217,34 +219,40 @@ static int preprocess_chunk(tstar_owl* h, const uint8_t* d_images, int B, int H,
 extern "C" {
 
 const char* tstar_last_error(void) { return g_err.c_str(); }
-int tstar_abi_version(void) { return 2; }
+int tstar_abi_version(void) { return 3; }
 size_t tstar_owl_vision_blob_floats(void) { return vision_floats(); }
 size_t tstar_owl_text_blob_floats(void) { return text_floats(); }
 
 static int make_bf16_copies(tstar_owl* h, int mode) {
-    std::vector<std::pair<const float*, size_t>> mats;
-    mats.push_back({h->vw.patch_w, (size_t)V_D * V_PATCH_K});
+    struct Mat { const float* w; int n, k; };
+    std::vector<Mat> mats;
+    mats.push_back({h->vw.patch_w, V_D, V_PATCH_K});
     auto layer = [&](const LayerW& l, int d, int ff) {
-        mats.push_back({l.qkv_w, (size_t)3 * d * d}); mats.push_back({l.out_w, (size_t)d * d});
-        mats.push_back({l.fc1_w, (size_t)ff * d}); mats.push_back({l.fc2_w, (size_t)d * ff});
+        mats.push_back({l.qkv_w, 3 * d, d}); mats.push_back({l.out_w, d, d});
+        mats.push_back({l.fc1_w, ff, d}); mats.push_back({l.fc2_w, d, ff});
     };
     for (int i = 0; i < V_LAYERS; ++i) layer(h->vw.layers[i], V_D, V_FF);
-    mats.push_back({h->vw.cls_w, (size_t)PROJ * V_D});
-    mats.push_back({h->vw.box0_w, (size_t)V_D * V_D});
-    mats.push_back({h->vw.box1_w, (size_t)V_D * V_D});
+    mats.push_back({h->vw.cls_w, PROJ, V_D});
+    mats.push_back({h->vw.box0_w, V_D, V_D});
+    mats.push_back({h->vw.box1_w, V_D, V_D});
     if (h->has_text) {
         for (int i = 0; i < T_LAYERS; ++i) layer(h->tw.layers[i], T_D, T_FF);
-        mats.push_back({h->tw.text_proj, (size_t)PROJ * T_D});
+        mats.push_back({h->tw.text_proj, PROJ, T_D});
     }
     for (auto& m : mats) {
-        __bf16 *p = nullptr, *lo = nullptr;
-        TSTAR_HIP_CHECK(hipMalloc(&p, m.second * sizeof(__bf16)));
-        h->wb[m.first] = p;
-        if (mode == TSTAR_WEIGHTS_F32_SPLIT) {
-            TSTAR_HIP_CHECK(hipMalloc(&lo, m.second * sizeof(__bf16)));
-            h->wb_lo[m.first] = lo;
+        const size_t n = (size_t)m.n * m.k;
+        int rc;
+        if (mode == TSTAR_WEIGHTS_F32X3) {
+            void* p = nullptr;
+            TSTAR_HIP_CHECK(hipMalloc(&p, n * 6));
+            h->wp[m.w] = p;
+            rc = pack_weights_x3(m.w, p, m.n, m.k, 0);
+        } else {
+            __bf16* p = nullptr;
+            TSTAR_HIP_CHECK(hipMalloc(&p, n * sizeof(__bf16)));
+            h->wb[m.w] = p;
+            rc = convert_f32_to_bf16(m.w, p, nullptr, n, 0);
         }
-        int rc = convert_f32_to_bf16(m.first, p, lo, m.second, 0);
         if (rc) return rc;
     }
     TSTAR_HIP_CHECK(hipDeviceSynchronize());
@@ -258,8 +266,9 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
     TSTAR_REQUIRE(!h_vision_blob || h_norm_lut, "tstar_owl_create: the vision tower needs the normalisation LUT");
     TSTAR_REQUIRE(h_vision_blob || weights_mode == TSTAR_WEIGHTS_F32, "tstar_owl_create: a text-only handle runs in float32");
     TSTAR_REQUIRE(max_batch >= 1 && max_batch <= 1024, "tstar_owl_create: max_batch must be in 1..1024");
-    TSTAR_REQUIRE(weights_mode >= TSTAR_WEIGHTS_F32 && weights_mode <= TSTAR_WEIGHTS_BF16_EXACT,
-                  "tstar_owl_create: weights_mode must be 0 (f32), 1 (bf16), 2 (f32 split) or 3 (bf16, exact three-term activations)");
+    TSTAR_REQUIRE(weights_mode == TSTAR_WEIGHTS_F32 || weights_mode == TSTAR_WEIGHTS_BF16 || weights_mode == TSTAR_WEIGHTS_BF16_EXACT ||
+                      weights_mode == TSTAR_WEIGHTS_F32X3,
+                  "tstar_owl_create: weights_mode must be 0 (f32), 1 (bf16), 3 (bf16, exact three-term activations) or 4 (f32x3); 2 (f32 split) was retired in ABI 3");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         set_error("tstar_owl_create: no HIP device visible (this library has no CPU path)");
@@ -317,7 +326,7 @@ int tstar_owl_destroy(tstar_owl* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : h->tabs) free_table(&kv.second);
     for (auto& kv : h->wb) if (kv.second) (void)hipFree(kv.second);
-    for (auto& kv : h->wb_lo) if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : h->wp) if (kv.second) (void)hipFree(kv.second);
     delete h;
     return TSTAR_OK;
 }
@@ -600,28 +609,21 @@ int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const flo
     return gemm_f32(g, (hipStream_t)stream);
 }
 
-static int gemm_converted(const char* fn, bool split, int a_terms, const float* d_A, const float* d_W, float* d_C, const float* d_bias,
+static int gemm_converted(const char* fn, int a_terms, const float* d_A, const float* d_W, float* d_C, const float* d_bias,
                           const float* d_residual, int M, int N, int K, int act, int tile_cfg, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    __bf16 *wb = nullptr, *lo = nullptr;
+    __bf16* wb = nullptr;
     TSTAR_HIP_CHECK(hipMalloc(&wb, (size_t)N * K * sizeof(__bf16)));
-    if (split && hipMalloc(&lo, (size_t)N * K * sizeof(__bf16)) != hipSuccess) {
-        (void)hipFree(wb);
-        set_error(std::string(fn) + ": out of device memory");
-        return TSTAR_ERR_HIP;
-    }
-    int rc = convert_f32_to_bf16(d_W, wb, lo, (size_t)N * K, s);
+    int rc = convert_f32_to_bf16(d_W, wb, nullptr, (size_t)N * K, s);
     if (!rc) {
         GemmArgs g = mk_gemm(nullptr, d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
         g.Wb = wb;
-        g.Wb2 = lo;
         g.a_terms = a_terms;
         g.tile_cfg = tile_cfg;
         rc = gemm_f32(g, s);
     }
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(wb);
-    if (lo) (void)hipFree(lo);
     if (!rc && e != hipSuccess) { set_error(std::string(fn) + ": " + hipGetErrorString(e)); rc = TSTAR_ERR_HIP; }
     return rc;
 }
@@ -629,7 +631,7 @@ static int gemm_converted(const char* fn, bool split, int a_terms, const float* 
 int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
                      int N, int K, int act, int tile_cfg, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_bf16w: null argument");
-    return gemm_converted("tstar_gemm_bf16w", false, 0, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
+    return gemm_converted("tstar_gemm_bf16w", 0, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
 }
 
 int tstar_gemm_bf16w_pre(const float* d_A, const void* d_Wb, float* d_C, const float* d_bias, const float* d_residual, int M, int N,
@@ -646,13 +648,27 @@ int tstar_gemm_bf16w_pre(const float* d_A, const void* d_Wb, float* d_C, const f
 int tstar_gemm_bf16w2(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
                       int N, int K, int act, int tile_cfg, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_bf16w2: null argument");
-    return gemm_converted("tstar_gemm_bf16w2", false, 2, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
+    return gemm_converted("tstar_gemm_bf16w2", 2, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
 }
 
-int tstar_gemm_f32_split(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
-                         int N, int K, int act, int tile_cfg, void* stream) {
-    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32_split: null argument");
-    return gemm_converted("tstar_gemm_f32_split", true, 0, d_A, d_W, d_C, d_bias, d_residual, M, N, K, act, tile_cfg, stream);
+int tstar_gemm_f32x3(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
+                     int N, int K, int act, int tile_cfg, void* stream) {
+    TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32x3: null argument");
+    TSTAR_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "tstar_gemm_f32x3: N must be a multiple of 32, K of 16");
+    hipStream_t s = (hipStream_t)stream;
+    void* wp = nullptr;
+    TSTAR_HIP_CHECK(hipMalloc(&wp, (size_t)N * K * 6));
+    int rc = pack_weights_x3(d_W, wp, N, K, s);
+    if (!rc) {
+        GemmArgs g = mk_gemm(nullptr, d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
+        g.Wp = wp;
+        g.tile_cfg = tile_cfg;
+        rc = gemm_f32(g, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(wp);
+    if (!rc && e != hipSuccess) { set_error(std::string("tstar_gemm_f32x3: ") + hipGetErrorString(e)); rc = TSTAR_ERR_HIP; }
+    return rc;
 }
 
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream) {

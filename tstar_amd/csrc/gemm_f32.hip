@@ -229,10 +229,8 @@ __device__ __forceinline__ void split4_bf16x2(const f32x4 v, u32x2 (&out)[2]) {
 }
 
 // WMODE 1: bf16 weights (Wb), activations split exactly into 3 terms.
-// WMODE 2: "f32 split" -- f32 weights pre-split into two bf16 arrays (Wb = hi, Wb2 = lo, round to
-//          nearest), activations split into 2 terms, C += a_lo*w_hi + a_hi*w_lo + a_hi*w_hi (the
-//          a_lo*w_lo term, 2^-18 relative, is dropped): 3 MFMAs per K = 16 like mode 1, operands
-//          carry 16 significand bits, products are exact, accumulation is f32.
+// (WMODE 2, the round-1..3 "f32 split" of both operands into two bf16 terms, is retired: the f32x3 tile below carries
+//  all 24 bits of both operands.)
 // WMODE 3: bf16 weights (exact in ONE term), activations as TWO round-to-nearest bf16 terms a_hi + a_lo
 //          (16 significand bits, |a - a_hi - a_lo| <= 2^-17 |a|): C += a_lo*w + a_hi*w, 2 MFMAs per K = 16
 //          instead of 3.  Products are exact, accumulation is f32; the dropped third term is 2^-17 relative
@@ -246,7 +244,7 @@ __device__ __forceinline__ void split4_bf16x2(const f32x4 v, u32x2 (&out)[2]) {
 template <class CF, int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0, const int n0, float* smem_f) {
     constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM, BN = CF::BN;
-    constexpr int NAT = WMODE == 1 ? 3 : 2, NWT = WMODE == 2 ? 2 : 1;     // operand terms
+    constexpr int NAT = WMODE == 1 ? 3 : 2, NWT = 1;                      // operand terms
     constexpr int NPROD = WMODE == 3 ? 2 : 3;                             // MFMA products per algorithmic product
     constexpr int DEPTH = TN >= 4 ? 1 : 2;                                // register prefetch depth in K tiles
     constexpr int A_T = BM * 64, W_T = BN * 64, BUF = NAT * A_T + NWT * W_T;       // bytes
@@ -289,7 +287,6 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             rb[st][0][i] = *reinterpret_cast<const u32x4*>(g.Wb + bo[i] + kt * BK);
-            if constexpr (NWT == 2) rb[st][NWT - 1][i] = *reinterpret_cast<const u32x4*>(g.Wb2 + bo[i] + kt * BK);
         }
     };
     auto lstore = [&](auto SET, int buf) __attribute__((always_inline)) {
@@ -326,11 +323,10 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     fw[w][j] = *reinterpret_cast<const bf16x8*>(base + NAT * A_T + w * W_T + bfw_off(wn * TN * 32 + j * 32 + l31, 2 * s + h));
-            // smallest term first: mode 1 a2*w, a1*w, a0*w; mode 2 a_lo*w_hi, a_hi*w_lo, a_hi*w_hi; mode 3 a_lo*w, a_hi*w
+            // smallest term first: mode 1 a2*w, a1*w, a0*w; mode 3 a_lo*w, a_hi*w
 #pragma unroll
             for (int p = NPROD - 1; p >= 0; --p) {
-                const int ka = WMODE == 2 ? (p == 2 ? 1 : 0) : p;
-                const int kw = WMODE == 2 ? (p == 1 ? 1 : 0) : 0;
+                const int ka = p, kw = 0;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -375,6 +371,173 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
         __syncthreads();
     }
     gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// f32x3 tile (WMODE 4, weights_dtype "f32x3", round 4): an f32 x f32 product on the bf16 matrix pipe with ALL 24
+// significand bits of both operands.  a = a0 + a1 + a2 and w = w0 + w1 + w2 exactly, each term a round-to-nearest
+// bfloat16 of the running remainder (8 + 8 + 8 bits with signed remainders; v_cvt_pk_bf16_f32), and
+//     C += a0 w2 + (a1 w1 + a0 w1) + (a2 w0 + a1 w0 + a0 w0)          per K = 16 step, smallest terms first,
+// the six partial products with ka + kw <= 2 on v_mfma_f32_32x32x16_bf16 (each product exact, f32 accumulation).  The
+// three products left out (a1 w2, a2 w1, a2 w2) are each <= 2^-24 |a w| and zero-mean: two orders below the rounding of
+// the f32 accumulation itself.  Measured against float64 on the same inputs (tools/lab/frag_lab.hip,
+// profiles/r04_frag_lab.log; tests/test_gpu_kernels.py::test_gemm_f32x3 asserts it): rms error 3.48e-7 (K = 768) /
+// 1.44e-6 (K = 3072) -- the SAME four digits as the nine-product form, and below the native f32 MFMA tile's 4.14e-7 /
+// 1.64e-6 (its accumulator is rounded once per k, this one six times per 16 k).
+// Why six and not nine: nine 32-cycle products against eight 64-cycle f32 MFMAs is 1.78x on paper, but random operands
+// pull the bf16 pipe's clock to 1.6-1.7 GHz where the f32 MFMA keeps 2.3: the nine-product loop measures 133-145 TFLOP/s,
+// the native tile 132-138 (profiles/r04_frag_lab_counters.md).  Six products: 177-201.
+//
+// Main loop (different from the tiles above): the WEIGHT planes never touch LDS.  They are packed once per matrix in
+// MFMA-fragment order -- [n-tile of 32 columns][phase q = 3 * (k / 16) + ph][lane][8 bf16], plane 2 - ph, so a wave's
+// B operand of one phase is ONE contiguous 1-KB global_load_dwordx4 -- and stream global -> VGPR through a ring of three
+// fragment sets, two phases (24-48 MFMAs) ahead of their use.  LDS carries only the three activation planes (split while
+// staging, the swizzled 64-B rows of the tiles above): 12-18 MFMAs per loaded KB keep both the LDS (~0.3 busy) and the
+// vector-memory path (~0.5) off the critical path; waves are ready-and-waiting for the matrix pipe 65 % of their cycles.
+// (For the two-term bf16-weight mode the same loop is SLOWER than its LDS tile -- 4 MFMAs per loaded KB put the fragment
+// loads on the 64 B/clk vector-memory path at ~75 % -- so that mode keeps its tile: r04_frag_lab_counters.md.)
+template <int NA>
+__device__ __forceinline__ void split4_rn(const f32x4 v, u32x2 (&out)[NA]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        f32x2 x; x[0] = v[2 * p]; x[1] = v[2 * p + 1];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const bf16x2 b = __builtin_convertvector(x, bf16x2);
+            const unsigned hb = __builtin_bit_cast(unsigned, b);
+            out[k][p] = hb;
+            if (k + 1 < NA) {
+                x[0] = x[0] - __uint_as_float(hb << 16);                  // exact
+                x[1] = x[1] - __uint_as_float(hb & 0xFFFF0000u);
+            }
+        }
+    }
+}
+
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, const int n0, float* smem_f) {
+    constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM;
+    constexpr int NT = 3, D = 3, PPT = 2 * NT;                            // planes per operand, ring depth, phases per K tile
+    constexpr int A_T = BM * 64, BUF = NT * A_T;                          // bytes
+    char* smem = reinterpret_cast<char*>(smem_f);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    constexpr int NA = BM / 32;
+    const int c4 = t & 7, r0 = t >> 3;
+    const float* ap[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int ar = m0 + r0 + 32 * i;
+        ar = ar < g.M ? ar : g.M - 1;
+        ap[i] = g.A + (size_t)ar * g.lda + c4 * 4;
+    }
+    const int nph = (g.K / 16) * NT;                                     // KB per n-tile stream
+    const char* wb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        wb[j] = static_cast<const char*>(g.Wp) + (size_t)((n0 >> 5) + wn * TN + j) * nph * 1024 + lane * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NA];
+    u32x4 ring[D][TN];
+    auto gload_a = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            u32x2 sp[NT];
+            split4_rn<NT>(ra[i], sp);
+            const int off = bfw_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
+        }
+    };
+    const int nk = g.K / BK;
+    gload_a(0);
+#pragma unroll
+    for (int q = 0; q < D - 1; ++q)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) ring[q][j] = *reinterpret_cast<const u32x4*>(wb[j] + (size_t)(q < nph ? q : nph - 1) * 1024);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload_a(kt + 1);
+        const char* base = smem + (kt & 1) * BUF;
+        __builtin_amdgcn_s_setprio(1);
+        bf16x8 fa[NT][TM];
+#pragma unroll
+        for (int P = 0; P < PPT; ++P) {
+            const int s = P / NT, ph = P % NT, kw = NT - 1 - ph;
+            {   // refill the ring two phases ahead (the last phases of the last tile re-read the final KB: never used)
+                int q = kt * PPT + P + D - 1;
+                q = q < nph ? q : nph - 1;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) ring[(P + D - 1) % D][j] = *reinterpret_cast<const u32x4*>(wb[j] + (size_t)q * 1024);
+            }
+            if (ph == 0) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[k][i] = *reinterpret_cast<const bf16x8*>(base + k * A_T + bfw_off(wm * TM * 32 + i * 32 + l31, 2 * s + h));
+            }
+#pragma unroll
+            for (int ka = NT - 1; ka >= 0; --ka) {
+                if (ka + kw > 2) continue;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ka][i], __builtin_bit_cast(bf16x8, ring[P % D][j]), acc[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+    gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
+}
+
+// Wp[n-tile][q = 3 * ks + ph][lane][e] = plane (2 - ph) of W[32 n-tile + (lane & 31)][16 ks + 8 (lane >> 5) + e]; one thread per
+// (row, 8-k chunk): 32 B read, three 16-B stores.
+__global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ W, char* __restrict__ Wp, int N, int K) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int kc = K / 8;
+    if (gid >= (size_t)N * kc) return;
+    const int n = (int)(gid / kc), c = (int)(gid % kc);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + c * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + c * 8 + 4);
+    u32x2 s0[3], s1[3];
+    split4_rn<3>(v0, s0);
+    split4_rn<3>(v1, s1);
+    const int ks = c >> 1, hh = c & 1, nph = (K / 16) * 3;
+#pragma unroll
+    for (int ph = 0; ph < 3; ++ph) {
+        u32x4 o;
+        o[0] = s0[2 - ph][0]; o[1] = s0[2 - ph][1]; o[2] = s1[2 - ph][0]; o[3] = s1[2 - ph][1];
+        *reinterpret_cast<u32x4*>(Wp + (((size_t)(n >> 5) * nph + ks * 3 + ph) * 64 + hh * 32 + (n & 31)) * 16) = o;
+    }
+}
+
+int pack_weights_x3(const float* W, void* Wp, int N, int K, hipStream_t s) {
+    TSTAR_REQUIRE(N % 32 == 0 && K % 16 == 0, "pack_weights_x3: N must be a multiple of 32, K of 16");
+    const size_t n = (size_t)N * (K / 8);
+    hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, static_cast<char*>(Wp), N, K);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
 }
 
 // One output tile of shape CF at (m0, n0).  `smem` is the block's dynamic LDS.
@@ -474,7 +637,8 @@ __global__ __launch_bounds__(256, CF::MINW) void gemm_f32_kernel(GemmArgs g) {
     const int nt = g.N / CF::BN;
     const int mt = (g.M + CF::BM - 1) / CF::BM;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
-    if (WMODE) gemm_tile_bf16w<CF, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
+    if constexpr (WMODE == 4) gemm_tile_x3<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
+    else if constexpr (WMODE != 0) gemm_tile_bf16w<CF, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
     else gemm_tile<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
 }
 
@@ -488,43 +652,47 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_hybrid_kernel(GemmArgs g) {
     const int n_big = (g.m_split / 128) * nt;
     if ((int)blockIdx.x < n_big) {
         const int tile = xcd_remap(blockIdx.x, n_big);
-        if (WMODE) gemm_tile_bf16w<Cfg128, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
+        if constexpr (WMODE == 4) gemm_tile_x3<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
+        else if constexpr (WMODE != 0) gemm_tile_bf16w<Cfg128, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
         else gemm_tile<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
     } else {
         const int n_small = gridDim.x - n_big;
         const int tile = xcd_remap(blockIdx.x - n_big, n_small);
-        if (WMODE) gemm_tile_bf16w<Cfg64N, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        if constexpr (WMODE == 4) gemm_tile_x3<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        else if constexpr (WMODE != 0) gemm_tile_bf16w<Cfg64N, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
         else gemm_tile<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
     }
 }
 
-// Wide hybrid launch of the two-term bf16-weight mode: rows [0, m_split) in 128x256 tiles (whole waves of the 512
+// Wide hybrid launch of the two-term bf16-weight mode (WMODE 3) and of the f32x3 mode (WMODE 4): rows [0, m_split) in 128x256 tiles (whole waves of the 512
 // resident slots), the remaining rows in 64x128 tiles that arrive last and fill the tail.
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w2_wide_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ntw = g.N / 256;
     const int n_big = (g.m_split / 128) * ntw;
     if ((int)blockIdx.x < n_big) {
         const int tile = xcd_remap(blockIdx.x, n_big);
-        gemm_tile_bf16w<Cfg128W, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / ntw) * 128, (tile % ntw) * 256, smem);
+        if constexpr (WMODE == 4) gemm_tile_x3<Cfg128W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / ntw) * 128, (tile % ntw) * 256, smem);
+        else gemm_tile_bf16w<Cfg128W, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / ntw) * 128, (tile % ntw) * 256, smem);
     } else {
         const int nt = g.N / 128;
         const int n_small = gridDim.x - n_big;
         const int tile = xcd_remap(blockIdx.x - n_big, n_small);
-        gemm_tile_bf16w<Cfg64N, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        if constexpr (WMODE == 4) gemm_tile_x3<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        else gemm_tile_bf16w<Cfg64N, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
     }
 }
 
 // dynamic LDS of one block: double-buffered operand tiles
 template <int WMODE>
 constexpr int lds_bytes(int bm, int bn) {
-    return WMODE == 3 ? 2 * (2 * bm + bn) * 64 : WMODE == 2 ? 2 * (2 * bm + 2 * bn) * 64 : WMODE == 1 ? 2 * (3 * bm + bn) * 64 : 2 * (bm + bn) * LDS_LD * 4;
+    return WMODE == 4 ? 2 * 3 * bm * 64 : WMODE == 3 ? 2 * (2 * bm + bn) * 64 : WMODE == 1 ? 2 * (3 * bm + bn) * 64 : 2 * (bm + bn) * LDS_LD * 4;
 }
 
 // algorithmic HBM bytes of one launch: A and W read once, C written once, residual read once, bias / position rows
 static double gemm_algorithmic_bytes(const GemmArgs& g) {
-    const double wbytes = g.Wb ? (g.Wb2 ? 4.0 : 2.0) : 4.0;            // bf16 weights: one term; f32-split: two bf16 terms
+    const double wbytes = g.Wp ? 6.0 : g.Wb ? 2.0 : 4.0;                // f32x3: three bf16 planes; bf16 weights: one term
     return 4.0 * g.M * g.K + wbytes * g.N * g.K + 4.0 * g.M * g.N * (g.res ? 2.0 : 1.0) + (g.bias ? 4.0 * g.N : 0.0) +
            (g.pos ? 4.0 * (g.patch_np + 1) * g.N : 0.0);
 }
@@ -558,10 +726,10 @@ static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
     return TSTAR_OK;
 }
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_wide(const GemmArgs& g, hipStream_t stream) {
-    constexpr int lds = lds_bytes<3>(128, 256);
-    auto kern = gemm_bf16w2_wide_kernel<ACT, HAS_BIAS, HAS_RES, PATCH>;
+    constexpr int lds = lds_bytes<WMODE>(128, 256);
+    auto kern = gemm_bf16w2_wide_kernel<WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>;
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     const int nwg = (g.m_split / 128) * (g.N / 256) + cdiv(g.M - g.m_split, 64) * (g.N / 128);
     const bool prof = prof_enabled();
@@ -615,8 +783,8 @@ static int pick_cfg(int M, int N, int* m_split) {
 template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_mode(const GemmArgs& g, hipStream_t stream) {
     const int forced = g.tile_cfg;                           // -1 = auto
-    if constexpr (WMODE == 3) {
-        // two-term mode: from one wave (512) of 128x256 tiles on, whole waves of them; the remaining full panels are wide
+    if constexpr (WMODE == 3 || WMODE == 4) {
+        // two-term mode (and the f32x3 mode, whose 128x256 tile measures 6-7 % above its 128x128 one: 197-201 vs 184-188 TFLOP/s): from one wave (512) of 128x256 tiles on, whole waves of them; the remaining full panels are wide
         // too when they make more than half a wave (a 64x128 tile of this mode is LDS-bound and runs at ~0.7 of the wide
         // tile's rate: three rounds of them cost more than one round of wide tiles -- tools/bench_gemm_bf16.py: out-proj
         // at B = 64, 864 wide tiles: 410 all wide vs 384 with a narrow tail), else they and the ragged rows go out as
@@ -631,7 +799,7 @@ static int launch_mode(const GemmArgs& g, hipStream_t stream) {
             if (big > 0 && fits32) {
                 GemmArgs h = g;
                 h.m_split = big * 128;
-                return launch_wide<ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
+                return launch_wide<WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
             }
         }
     }
@@ -657,7 +825,7 @@ static int launch_mode(const GemmArgs& g, hipStream_t stream) {
 
 template <int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 static int launch_one(const GemmArgs& g, hipStream_t stream) {
-    if (g.Wb && g.Wb2) return launch_mode<2, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
+    if (g.Wp) return launch_mode<4, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
     if (g.Wb && g.a_terms == 2) return launch_mode<3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
     if (g.Wb) return launch_mode<1, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
     return launch_mode<0, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);

@@ -10,7 +10,7 @@ struct GemmArgs {
     const float* A;      // [M, lda] row-major, K contiguous
     const float* W;      // [N, K] row-major (nn.Linear layout)
     const __bf16* Wb;    // optional bfloat16 copy of W: selects the bf16-weight tile (exact split of A)
-    const __bf16* Wb2;   // optional low term: W ~ Wb + Wb2 (both round-to-nearest) selects the f32-split tile
+    const void* Wp;      // optional fragment-packed three-plane copy of W (pack_weights_x3): selects the f32x3 tile
     float* C;            // [*, ldc]
     const float* bias;   // [N] or null
     const float* res;    // residual, same layout as C, or null (may alias C)
@@ -20,14 +20,16 @@ struct GemmArgs {
     int patch_np;        // patches per image (576) for the patch-embed epilogue
     int tile_cfg;        // -1 auto; 0 = 128x128, 1 = 64x128, 2 = 64x64 block tile, 3 = hybrid 128x128 + 64x128 tail (half/half); 16 + n = hybrid with n big row tiles (diagnostic)
     int m_split;         // hybrid launch: rows [0, m_split) use 128-row tiles (set by the launcher)
-    int a_terms;         // bf16-weight tile (Wb set, Wb2 null): 2 = activations as two round-to-nearest bf16 terms (2 MFMA
+    int a_terms;         // bf16-weight tile (Wb set): 2 = activations as two round-to-nearest bf16 terms (2 MFMA
                          // products per algorithmic product); anything else = the exact three-term split
 };
 int gemm_f32(const GemmArgs& g, hipStream_t stream);
 
-// Wb[i] = bfloat16(W[i]) (round to nearest even); n elements.  With Wlo != null also
-// Wlo[i] = bfloat16(W[i] - Wb[i]) (the two-term split of the f32-split mode).
+// Wb[i] = bfloat16(W[i]) (round to nearest even); n elements.  With Wlo != null also Wlo[i] = bfloat16(W[i] - Wb[i]).
 int convert_f32_to_bf16(const float* W, __bf16* Wb, __bf16* Wlo, size_t n, hipStream_t s);
+
+// f32x3 mode: W [N, K] f32 -> three exact bf16 planes in MFMA-fragment order, 6 * N * K bytes (gemm_f32.hip)
+int pack_weights_x3(const float* W, void* Wp, int N, int K, hipStream_t s);
 
 // y[r,:] = LayerNorm(x[r,:]) * w + b over D (eps 1e-5, biased variance); D % 256 == 0, D <= 1024
 int layernorm_f32(const float* x, float* y, const float* w, const float* b, int rows, int D, hipStream_t s);

@@ -101,8 +101,8 @@ class OWLInterface(HeuristicInterface):
         if allow_standin_tokenizer is None:
             allow_standin_tokenizer = self.weights_source.startswith("synthetic(")
         self.allow_standin_tokenizer = bool(allow_standin_tokenizer)
-        if weights_dtype not in ("f32", "bf16", "bf16_exact", "f32_split"):
-            raise ValueError("weights_dtype must be 'f32', 'bf16', 'bf16_exact' or 'f32_split'")
+        if weights_dtype not in ("f32", "bf16", "bf16_exact", "f32x3"):
+            raise ValueError("weights_dtype must be 'f32', 'bf16', 'bf16_exact' or 'f32x3'")
         if weights_dtype in ("bf16", "bf16_exact"):
             state_dict = W.round_weights_to_bf16(state_dict)
         self.weights_dtype = weights_dtype

@@ -51,7 +51,7 @@ class ScoreResult:
 class OwlScorer:
     """One OWL-ViT-B/32 scorer resident on the current HIP device."""
 
-    WEIGHTS_MODES = {"f32": 0, "bf16": 1, "f32_split": 2, "bf16_exact": 3}      # TSTAR_WEIGHTS_* of include/tstar_hip.h
+    WEIGHTS_MODES = {"f32": 0, "bf16": 1, "bf16_exact": 3, "f32x3": 4}      # TSTAR_WEIGHTS_* of include/tstar_hip.h
 
     def __init__(self, vision_blob: Optional[np.ndarray], text_blob: Optional[np.ndarray] = None, max_batch: int = 32,
                  weights_mode: str = "f32"):

@@ -29,13 +29,27 @@ class SplinePoolError(RuntimeError):
     pass
 
 
+def host_threads() -> int:
+    """Hardware threads this process may run on (its affinity mask / cgroup cpuset), not the machine's count: under a
+    container or a per-rank cpuset ``os.cpu_count()`` over-reports and 8 ranks would oversubscribe the host."""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return max(1, os.cpu_count() or 1)
+
+
 def default_workers() -> int:
-    """TSTAR_SPLINE_WORKERS, else up to 16 workers out of half this rank's share of the host threads."""
+    """TSTAR_SPLINE_WORKERS, else up to 16 workers out of half this rank's share of the host threads it may use.  When the
+    launcher has pinned each rank to its own cpuset the affinity mask already IS the rank's share; otherwise the mask is the
+    whole host and is divided by LOCAL_WORLD_SIZE -- so the node total stays <= half the usable threads either way."""
     env = os.environ.get("TSTAR_SPLINE_WORKERS")
     if env is not None:
         return max(0, int(env))
     ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    return max(1, min(16, (os.cpu_count() or 2) // (2 * ranks)))
+    usable = host_threads()
+    pinned = usable < (os.cpu_count() or usable)            # a narrower mask than the machine: assume it is per rank
+    share = usable if pinned and ranks > 1 else usable // ranks
+    return max(1, min(16, share // 2))
 
 
 class SplinePool:
@@ -56,6 +70,19 @@ class SplinePool:
 
     def __len__(self):
         return len(self._procs)
+
+    def cpu_seconds(self) -> float:
+        """user + system CPU seconds the worker processes have consumed so far (/proc/<pid>/stat fields 14, 15)."""
+        tck = float(os.sysconf("SC_CLK_TCK"))
+        total = 0.0
+        for p in self._procs:
+            try:
+                with open(f"/proc/{p.pid}/stat") as f:
+                    parts = f.read().rsplit(")", 1)[1].split()
+                total += (int(parts[11]) + int(parts[12])) / tck
+            except (OSError, IndexError, ValueError):
+                pass
+        return total
 
     def close(self):
         for p in self._procs:
