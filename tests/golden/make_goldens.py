@@ -11,6 +11,7 @@ No reference source is copied: only inputs and outputs are written.
     python tests/golden/make_goldens.py            (takes about 7 minutes on 8 cores)
     python tests/golden/make_goldens.py --only-g10
     python tests/golden/make_goldens.py --only-g11
+    python tests/golden/make_goldens.py --only-g9b          (about one minute)
 """
 import os
 import sys
@@ -238,7 +239,8 @@ def g2_to_g6(TStarSearcher):
     print("g2..g6 done")
 
 
-def g7_g8_g9(TStarSearcher):
+def build_reference_owl():
+    """The reference's OWLInterface (imported unmodified) over HF's OwlViTForObjectDetection with the seeded synthetic weights."""
     import torch
     from transformers import OwlViTConfig, OwlViTForObjectDetection
     from transformers.models.owlvit.image_processing_pil_owlvit import OwlViTImageProcessorPil
@@ -278,6 +280,11 @@ def g7_g8_g9(TStarSearcher):
 
     owl = RefOWL("google/owlvit-base-patch32", device="cpu")
     owl.reparameterize_object_list(["couch"], ["tv", "chair"])
+    return owl, ip, encode_queries
+
+
+def g7_g8_g9(TStarSearcher):
+    owl, ip, encode_queries = build_reference_owl()
     # G8 preprocess + G7 detector on two image shapes
     rs = np.random.RandomState(5)
     g7 = {}
@@ -299,8 +306,12 @@ def g7_g8_g9(TStarSearcher):
     np.savez_compressed(os.path.join(OUT, "g7_g8_detector.npz"), **g7)
     print("g7/g8 done")
     # G9 end-to-end: reference searcher + reference OWLInterface on the procedural video
-    N, g, K = 160, 4, 4
-    path = register_video(N, 5)
+    g9_run(TStarSearcher, owl, 160, 4, 4, 0.4, 5, 2025, "g9_end_to_end.npz")
+
+
+def g9_run(TStarSearcher, owl, N, g, K, budget, vseed, np_seed, out_name):
+    """One end-to-end run of the reference searcher driving the reference OWLInterface (HF transformers on the CPU)."""
+    path = register_video(N, vseed)
     conf_log = []
     orig = TStarSearcher.imageGridScoreFunction
 
@@ -310,9 +321,9 @@ def g7_g8_g9(TStarSearcher):
         return cm, names
 
     TStarSearcher.imageGridScoreFunction = logged
-    np.random.seed(2025)
+    np.random.seed(np_seed)
     s = TStarSearcher(video_path=path, heuristic=owl, target_objects=["couch"], cue_objects=["tv", "chair"], search_nframes=K,
-                      image_grid_shape=(g, g), search_budget=0.4, confidence_threshold=0.6)
+                      image_grid_shape=(g, g), search_budget=budget, confidence_threshold=0.6)
     secs_log = []
     orig_sf = s.sample_frames
     s.sample_frames = lambda num, _o=orig_sf: (lambda r: (secs_log.append(list(r[0])), r)[1])(_o(num))
@@ -320,13 +331,21 @@ def g7_g8_g9(TStarSearcher):
     TStarSearcher.imageGridScoreFunction = orig
     grid_conf = np.stack([c for (gr, c, n) in conf_log if gr == (g, g)])
     ver_conf = np.array([c[0, 0] for (gr, c, n) in conf_log if gr == (1, 1)])
-    np.savez_compressed(os.path.join(OUT, "g9_end_to_end.npz"), meta=np.array([N, g, K, 2025, 5, len(conf_log)], dtype=np.int64),
+    np.savez_compressed(os.path.join(OUT, out_name), meta=np.array([N, g, K, np_seed, vseed, len(conf_log)], dtype=np.int64),
+                        budget=np.float64(budget),
                         secs=np.array(secs_log, dtype=np.int64), time_stamps=np.asarray(ts, dtype=np.float64),
                         grid_conf=grid_conf, verify_conf=ver_conf,
                         grid_names=np.array(["|".join(sorted(set(x))) for (gr, c, n) in conf_log if gr == (g, g) for x in n]),
                         frames_sha=np.array([GU.sha(np.asarray(frames))]), score_final=np.asarray(s.score_distribution),
                         P_last=np.asarray(s.P_history[-1]))
-    print("g9 done: calls", len(conf_log), "ts", ts)
+    print(out_name, "done: calls", len(conf_log), "iterations", len(secs_log), "ts", ts)
+
+
+def g9b_hour_video(TStarSearcher):
+    """G9b (round 4, SURVEY 8c's 3600-frame end-to-end probe): the same reference pair on the 3600-frame procedural video at the
+    reference's default 4x4 grid and K = 8, the budget cut to three iterations (0.0133 * 3600 = 47.9 -> 31.9 -> 15.9 -> < 0)."""
+    owl, _, _ = build_reference_owl()
+    g9_run(TStarSearcher, owl, 3600, 4, 8, 0.0133, 9, 4242, "g9b_end_to_end_3600.npz")
 
 
 def g10_metrics():
@@ -403,6 +422,18 @@ def main():
     if "--only-g11" in sys.argv:
         g11_topk()
         return
+    if "--only-g9b" in sys.argv:
+        import matplotlib
+        matplotlib.use("Agg")
+        from TStar.interface_searcher import TStarSearcher
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                g9b_hour_video(TStarSearcher)
+            finally:
+                os.chdir(cwd)
+        return
     import matplotlib
     matplotlib.use("Agg")
     from TStar.interface_searcher import TStarSearcher
@@ -413,6 +444,7 @@ def main():
             g1_searcher(TStarSearcher)
             g2_to_g6(TStarSearcher)
             g7_g8_g9(TStarSearcher)
+            g9b_hour_video(TStarSearcher)
             g10_metrics()
             g11_topk()
         finally:

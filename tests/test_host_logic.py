@@ -484,3 +484,95 @@ def test_compressed_sequence_front_end(tmp_path):
         V.open_video(str(tmp_path / "still.png"), device="cpu")
     with pytest.raises(ValueError, match="Cannot open video file"):
         V.open_video(str(tmp_path / "missing.webp"), device="cpu")
+
+
+def _reference_default_fit_problems():
+    """The 63 (visited frames, scores) fit problems of a reference-default search (N = 3600, 4x4 grid, 63 iterations): the oracle
+    searcher driven by the golden generator's fake detector (the G1 case-0 configuration)."""
+    import golden_util as GU
+    from oracle import searcher_ref as S
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g1_searcher_case0.npz"), allow_pickle=False)
+    n, grid, seed, K, np_seed, calls, iters = [int(v) for v in g["meta"]]
+    targets, cues = [str(t) for t in g["targets"]], [str(c) for c in g["cues"]]
+    h = GU.FakeHeuristic(seed, conf_scale=float(g["conf_scale"]))
+    h.reparameterize_object_list(targets, cues)
+    o2w = {**{t: 1.0 for t in targets}, **{c: 0.5 for c in cues}}
+
+    def score_fn(kind, secs, rows, cols):
+        H, W = (95 * rows, 200 * cols) if kind == "grid" else (285, 600)
+        det = h.inference_detector([np.zeros((H, W, 3), np.uint8)])[0]
+        return S.image_grid_score(det.xyxy, det.class_id, det.confidence, h.texts, o2w, H, W, rows, cols)
+
+    probs = []
+    orig = S.spline_distribution
+
+    def spy(unv, score):
+        vis = np.nonzero(unv == 0)[0]
+        probs.append((vis.astype(np.float64), score[vis].copy()))
+        return orig(unv, score)
+    S.spline_distribution = spy
+    try:
+        S.SearcherRef(n, 1.0, targets, cues, score_fn, np.random.RandomState(np_seed), search_nframes=K, image_grid_shape=(grid, grid),
+                      search_budget=float(g["budget"]), confidence_threshold=float(g["thr"])).search()
+    finally:
+        S.spline_distribution = orig
+    return probs
+
+
+def test_native_curfit_bit_identical_to_scipy(golden_dir):
+    """csrc/fitpack.cpp (round 4): FITPACK's curfit restated for the reference's one call, UnivariateSpline(x, y, s=0.5) --
+    knots t, coefficients c and the residual fp BIT-IDENTICAL to scipy's on (a) all 63 fits of a reference-default search
+    (16 .. 1008 points, up to ~800 knots, 3-11 smoothing-parameter iterations each), (b) golden G4's problems (the reference's
+    own spline_keyframe_distribution inputs) incl. P itself, (c) seeded random problems: tiny and ragged sizes, other s,
+    least-squares-polynomial (ier -2) and interpolation-limit cases; in the sequential, the AVX2 and the AVX-512 form of the
+    skewed rotation pipeline (a form the CPU lacks falls back to the next narrower one)."""
+    import warnings
+    from scipy.interpolate import UnivariateSpline
+    from tstar_amd import spline_worker as SW
+    assert SW.curfit(np.arange(8.0), np.arange(8.0) ** 2 % 3, 0.5) is not None, "libtstar_fitpack.so missing: run python -m tstar_amd.build"
+
+    def check(x, y, s, tag):
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            try:
+                sp = UnivariateSpline(x, y, s=s)
+            except Warning:
+                assert SW.curfit(x, y, s) is None, tag          # FITPACK warning: the native path steps aside, scipy raises it
+                return 0
+        t, c, k = sp._eval_args
+        for lanes in (1, 4, 8):
+            got = SW.curfit(x, y, s, lanes)
+            assert got is not None, (tag, lanes)
+            tt, cc, kk, fp, ier = got
+            assert kk == 3 and len(tt) == len(t) and np.array_equal(tt, t), (tag, lanes, len(tt), len(t))
+            assert np.array_equal(cc[:len(t) - 4], c[:len(t) - 4]) and fp == sp.get_residual(), (tag, lanes)
+        return len(t)
+
+    probs = _reference_default_fit_problems()
+    assert len(probs) == 63 and len(probs[-1][0]) == 1008
+    knots = [check(x, y, 0.5, f"search fit {i}") for i, (x, y) in enumerate(probs)]
+    assert max(knots) > 700
+    g4 = np.load(os.path.join(golden_dir, "g4_spline.npz"), allow_pickle=False)
+    for k in range(4):
+        unv, sc, P = g4[f"unv{k}"], g4[f"score{k}"], g4[f"P{k}"]
+        vis = np.nonzero(unv == 0)[0]
+        check(vis.astype(np.float64), sc[vis], 0.5, f"g4 case {k}")
+        got = SW.spline_distribution(vis, sc[vis], len(sc))
+        assert np.abs(got - P).max() <= 4 * np.finfo(np.float64).eps * P.max()       # numpy exp's last-place freedom across CPUs (as the G4 test)
+        os.environ["TSTAR_NATIVE_FIT"] = "0"
+        try:
+            SW._FIT = None
+            ref = SW.spline_distribution(vis, sc[vis], len(sc))                         # scipy's fit on THIS machine
+        finally:
+            del os.environ["TSTAR_NATIVE_FIT"]
+            SW._FIT = None
+        assert np.array_equal(got, ref), k
+    rs = np.random.RandomState(404)
+    for trial in range(120):
+        m = int(rs.choice([4, 5, 6, 7, 8, 9, 12, 16, 17, 18, 31, 33, 48, 100, 257, 400]))
+        x = np.sort(rs.choice(3600, size=m, replace=False)).astype(np.float64)
+        kind = trial % 4
+        y = (rs.random_sample(m) ** 6 * 0.5 if kind == 0 else rs.random_sample(m) * (1e-3 if kind == 1 else 2.0) if kind < 3
+             else np.linspace(0.1, 0.4, m) + 1e-6 * rs.standard_normal(m))
+        s = float(rs.choice([0.5, 0.5, 0.05, 5.0, 1e-4]))
+        check(x, y, s, f"random {trial} m={m} s={s}")

@@ -118,3 +118,39 @@ def test_g11_topk_selection_matches_reference(golden_dir):
         assert len(got) == min(k, len(dc)), name
         n_cut += GU.check_topk_against_reference(got, ref, dc, start)
     assert n_cut >= 3          # the flat / all-zero / plateau cases do cut through ties
+
+
+@pytest.mark.parametrize("name", ["g9_end_to_end.npz", "g9b_end_to_end_3600.npz"])
+def test_oracle_pipeline_free_running_vs_reference_end_to_end(golden_dir, name):
+    """L3 on the CPU (round 4): the WHOLE oracle pipeline -- ingest restatement, OWL-ViT restatement, cell aggregation,
+    searcher restatement -- run closed-loop against the reference's own end-to-end runs (reference searcher + reference
+    OWLInterface on HF transformers; G9: 160 frames / 4 iterations / 48 detector calls, G9b: the 3600-frame video at the
+    reference-default 4x4 grid, K = 8, 3 iterations / 29 calls).  Same sampled seconds in every iteration, every cell and
+    verification confidence within 1e-5, same keyframes, same final score distribution: the oracle the GPU tests are
+    teacher-forced through follows the reference end to end at the bench's video length."""
+    from oracle import cpu_pipeline
+    from tstar_amd import weights as W
+    from tstar_amd.tokenizer import encode_queries
+    from tstar_amd.video import synthetic_frames_numpy
+    g = _load(golden_dir, name)
+    N, grid, K, np_seed, vseed, ncalls = [int(v) for v in g["meta"]]
+    budget = float(g["budget"]) if "budget" in g.files else 0.4
+    targets, cues = ["couch"], ["tv", "chair"]
+    det = cpu_pipeline.CpuOwlDetector(W.synthetic_state_dict(0), faithful=False)     # cached text tower: the same numbers
+    texts = [[t] for t in targets + cues] + [[" "]]
+    ids, am = encode_queries(texts)
+    det.reparameterize_object_list(targets, cues, ids, am)
+    log = []
+    score_fn = cpu_pipeline.make_score_fn(det, lambda secs: synthetic_frames_numpy(list(secs), N, seed=vseed),
+                                          {"couch": 1.0, "tv": 0.5, "chair": 0.5}, log)
+    ref = S.SearcherRef(N, 1.0, targets, cues, score_fn, np.random.RandomState(np_seed), search_nframes=K,
+                        image_grid_shape=(grid, grid), search_budget=budget, confidence_threshold=0.6)
+    ts = ref.search()
+    assert [it["secs"] for it in ref.trace] == g["secs"].tolist()
+    assert len(log) == ncalls
+    gc = np.stack([c["conf"] for c in log if c["kind"] == "grid"])
+    vc = np.array([c["conf"][0, 0] for c in log if c["kind"] == "verify"])
+    assert gc.shape == g["grid_conf"].shape and np.abs(gc - g["grid_conf"]).max() < 1e-5
+    assert vc.shape == g["verify_conf"].shape and (vc.size == 0 or np.abs(vc - g["verify_conf"]).max() < 1e-5)
+    assert ts == g["time_stamps"].tolist()
+    assert np.abs(ref.score - g["score_final"]).max() < 1e-5

@@ -18,6 +18,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libtstar_hip.so")
+FIT_LIB = os.path.join(HERE, "libtstar_fitpack.so")     # host-only (no HIP runtime): the spline workers load it in a fraction of a second
+FIT_SRC = os.path.join(CSRC, "fitpack.cpp")
+# -ffp-contract=off: the FITPACK restatement is bit-identical to scipy's only without fused multiply-adds;
+# -fno-math-errno lets sqrt vectorise and changes no result; never -ffast-math
+FIT_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-math-errno", "-Wall"]
 ARCH = "gfx950"
 
 # -ffp-contract=off on the searcher file keeps its float64 arithmetic bit-identical
@@ -70,6 +75,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     need_link = force or jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
     if need_link:
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+    if force or not os.path.exists(FIT_LIB) or os.path.getmtime(FIT_LIB) < os.path.getmtime(FIT_SRC):
+        gxx = os.environ.get("CXX") or shutil.which("g++")
+        if not gxx:
+            raise RuntimeError("g++ not found (set CXX)")
+        run([gxx] + FIT_FLAGS + [FIT_SRC, "-o", FIT_LIB])
     return LIB
 
 

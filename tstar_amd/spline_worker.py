@@ -14,8 +14,56 @@ The fit is exactly the call the reference makes -- ``UnivariateSpline(x, y, s=s)
 (/root/reference/TStar/interface_searcher.py:265) -- through the same scipy, so (t, c, k) and P are bit-identical
 to an in-process evaluation.
 """
+import os
 import struct
 import sys
+
+_FIT = None          # ctypes handle of libtstar_fitpack.so, False = unavailable / disabled
+
+
+def _native_fit():
+    """tstar_amd/libtstar_fitpack.so (csrc/fitpack.cpp: FITPACK's curfit restated operation for operation, its O(n^2)
+    smoothing-parameter step run as a skewed SIMD pipeline; (t, c, fp) bit-identical to scipy's, 4-10x faster on late
+    fits), or None -- then the same scipy call the reference makes is used.  TSTAR_NATIVE_FIT=0 disables it."""
+    global _FIT
+    if _FIT is None:
+        _FIT = False
+        if os.environ.get("TSTAR_NATIVE_FIT", "1") != "0":
+            import ctypes as C
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtstar_fitpack.so")
+            try:
+                lib = C.CDLL(path)
+                lib.tstar_curfit.restype = C.c_int
+                lib.tstar_curfit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+                _FIT = lib
+            except OSError:
+                pass
+    return _FIT or None
+
+
+def curfit(x, y, s: float = 0.5, lanes: int = 0):
+    """UnivariateSpline(x, y, s=s)._eval_args through the native restatement: (t [n], c [n] (the last 4 entries unused, zero),
+    k = 3, fp, ier), or None when the library is absent, the input is outside what it restates (fewer than 4 points, not
+    strictly increasing) or FITPACK reports a warning (ier > 0: scipy must raise it the way the reference sees it)."""
+    lib = _native_fit()
+    if lib is None:
+        return None
+    import ctypes as C
+    import numpy as np
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    m = len(x)
+    if m < 4 or x.shape != y.shape or x.ndim != 1 or not (np.isfinite(x).all() and np.isfinite(y).all()):
+        return None
+    t = np.zeros(m + 4)
+    c = np.zeros(m + 4)
+    n, fp, it = C.c_int(0), C.c_double(0.0), C.c_int(0)
+    ier = lib.tstar_curfit(x.ctypes.data, y.ctypes.data, m, float(s), int(lanes), t.ctypes.data, c.ctypes.data, C.byref(n),
+                           C.byref(fp), C.byref(it))
+    if ier not in (0, -1, -2):
+        return None
+    return t[:n.value], c[:n.value], 3, fp.value, ier
 
 
 def spline_distribution(visited_indices, observed_scores, video_length: int, s: float = 0.5):
@@ -25,11 +73,18 @@ def spline_distribution(visited_indices, observed_scores, video_length: int, s: 
     same numpy / scipy calls as the reference, on the host: P is bit-identical to the reference's on the same
     machine by construction (a device exp() could differ from numpy's in the last place)."""
     import numpy as np
-    from scipy.interpolate import UnivariateSpline
     if len(visited_indices) == 0:
         return np.ones(video_length) / video_length
-    spline = UnivariateSpline(visited_indices, observed_scores, s=s)
-    spline_scores = spline(np.arange(video_length))
+    fit = curfit(visited_indices, observed_scores, s)
+    if fit is not None:
+        # the same (t, c, k) scipy's fit returns, bit for bit (tests/test_host_logic.py); evaluated by the same scipy splev
+        # that UnivariateSpline.__call__ runs
+        from scipy.interpolate import splev
+        spline_scores = splev(np.arange(video_length), fit[:3])
+    else:
+        from scipy.interpolate import UnivariateSpline
+        spline = UnivariateSpline(visited_indices, observed_scores, s=s)
+        spline_scores = spline(np.arange(video_length))
     adjusted = np.maximum(1 / video_length, spline_scores)
     p = 1 / (1 + np.exp(-adjusted))
     p /= p.sum()
@@ -62,7 +117,8 @@ def main():
                 P = np.ascontiguousarray(spline_distribution(x, y, int(N), s), dtype=np.float64)
                 out.write(struct.pack("<qqq", 0, 8 * len(P), -1) + P.tobytes())
             else:
-                t, c, k = UnivariateSpline(x, y, s=s)._eval_args
+                fit = curfit(x, y, s)
+                t, c, k = fit[:3] if fit is not None else UnivariateSpline(x, y, s=s)._eval_args
                 t = np.ascontiguousarray(t, dtype=np.float64)
                 cc = np.zeros(len(t), dtype=np.float64)
                 cc[:len(c)] = c
