@@ -36,6 +36,21 @@ namespace tstar {
 
 constexpr int BK = 32, LDS_LD = BK + 4;
 
+// Linear tile index -> (row tile, column tile).  gm <= 1: row-panel major (all column tiles of a row panel are consecutive).
+// gm > 1: SUPER-PANELS of gm row panels, column-major inside one -- the ~64 tiles an XCD has in flight then form a
+// gm x (64 / gm) patch that shares gm A panels and 64 / gm W tiles in that XCD's L2, instead of one or two A panels against
+// every W tile: with the panel-major order a wide layer (fc1: 24 column tiles) re-streams the whole weight matrix from the
+// Infinity Cache for every 2-3 row panels (profiles/r03_pmc_gemm_traffic.json: 2.5x the algorithmic bytes per launch).
+__device__ __forceinline__ void tile_mn(int tile, int mt, int nt, int gm, int& mi, int& ni) {
+    if (gm <= 1) { mi = tile / nt; ni = tile - mi * nt; return; }
+    const int per = gm * nt;
+    const int sp = tile / per, r = tile - sp * per;
+    const int left = mt - sp * gm;
+    const int rows = left < gm ? left : gm;              // the last super-panel may be short
+    ni = r / rows;
+    mi = sp * gm + (r - ni * rows);
+}
+
 __device__ __forceinline__ float epi_act(float v, int act) {
     // quick_gelu(v) = v * sigmoid(1.702 v); exp through the raw v_exp_f32 (2^x, ~1 ulp): the epilogue runs
     // and the reciprocal through v_rcp_f32 (1 ulp): the epilogue runs while the matrix pipe idles, so its VALU
@@ -637,9 +652,11 @@ __global__ __launch_bounds__(256, CF::MINW) void gemm_f32_kernel(GemmArgs g) {
     const int nt = g.N / CF::BN;
     const int mt = (g.M + CF::BM - 1) / CF::BM;
     const int tile = xcd_remap(blockIdx.x, mt * nt);
-    if constexpr (WMODE == 4) gemm_tile_x3<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
-    else if constexpr (WMODE != 0) gemm_tile_bf16w<CF, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
-    else gemm_tile<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * CF::BM, (tile % nt) * CF::BN, smem);
+    int mi, ni;
+    tile_mn(tile, mt, nt, g.group_m, mi, ni);
+    if constexpr (WMODE == 4) gemm_tile_x3<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * CF::BM, ni * CF::BN, smem);
+    else if constexpr (WMODE != 0) gemm_tile_bf16w<CF, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * CF::BM, ni * CF::BN, smem);
+    else gemm_tile<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * CF::BM, ni * CF::BN, smem);
 }
 
 // Hybrid launch: rows [0, m_split) in 128x128 tiles (whole waves of the 512 resident slots), the
@@ -652,15 +669,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_hybrid_kernel(GemmArgs g) {
     const int n_big = (g.m_split / 128) * nt;
     if ((int)blockIdx.x < n_big) {
         const int tile = xcd_remap(blockIdx.x, n_big);
-        if constexpr (WMODE == 4) gemm_tile_x3<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
-        else if constexpr (WMODE != 0) gemm_tile_bf16w<Cfg128, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
-        else gemm_tile<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / nt) * 128, (tile % nt) * 128, smem);
+        int mi, ni;
+        tile_mn(tile, g.m_split / 128, nt, g.group_m, mi, ni);
+        if constexpr (WMODE == 4) gemm_tile_x3<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * 128, ni * 128, smem);
+        else if constexpr (WMODE != 0) gemm_tile_bf16w<Cfg128, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * 128, ni * 128, smem);
+        else gemm_tile<Cfg128, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * 128, ni * 128, smem);
     } else {
         const int n_small = gridDim.x - n_big;
         const int tile = xcd_remap(blockIdx.x - n_big, n_small);
-        if constexpr (WMODE == 4) gemm_tile_x3<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
-        else if constexpr (WMODE != 0) gemm_tile_bf16w<Cfg64N, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
-        else gemm_tile<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        int mi, ni;
+        tile_mn(tile, n_small / nt, nt, g.group_m, mi, ni);
+        if constexpr (WMODE == 4) gemm_tile_x3<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + mi * 64, ni * 128, smem);
+        else if constexpr (WMODE != 0) gemm_tile_bf16w<Cfg64N, WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + mi * 64, ni * 128, smem);
+        else gemm_tile<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + mi * 64, ni * 128, smem);
     }
 }
 
@@ -673,14 +694,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w2_wide_kernel(GemmArgs g) {
     const int n_big = (g.m_split / 128) * ntw;
     if ((int)blockIdx.x < n_big) {
         const int tile = xcd_remap(blockIdx.x, n_big);
-        if constexpr (WMODE == 4) gemm_tile_x3<Cfg128W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / ntw) * 128, (tile % ntw) * 256, smem);
-        else gemm_tile_bf16w<Cfg128W, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, (tile / ntw) * 128, (tile % ntw) * 256, smem);
+        int mi, ni;
+        tile_mn(tile, g.m_split / 128, ntw, g.group_m, mi, ni);
+        if constexpr (WMODE == 4) gemm_tile_x3<Cfg128W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * 128, ni * 256, smem);
+        else gemm_tile_bf16w<Cfg128W, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * 128, ni * 256, smem);
     } else {
         const int nt = g.N / 128;
         const int n_small = gridDim.x - n_big;
         const int tile = xcd_remap(blockIdx.x - n_big, n_small);
-        if constexpr (WMODE == 4) gemm_tile_x3<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
-        else gemm_tile_bf16w<Cfg64N, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + (tile / nt) * 64, (tile % nt) * 128, smem);
+        int mi, ni;
+        tile_mn(tile, n_small / nt, nt, g.group_m, mi, ni);
+        if constexpr (WMODE == 4) gemm_tile_x3<Cfg64N, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + mi * 64, ni * 128, smem);
+        else gemm_tile_bf16w<Cfg64N, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, g.m_split + mi * 64, ni * 128, smem);
     }
 }
 
@@ -831,7 +856,15 @@ static int launch_one(const GemmArgs& g, hipStream_t stream) {
     return launch_mode<0, ACT, HAS_BIAS, HAS_RES, PATCH>(g, stream);
 }
 
-int gemm_f32(const GemmArgs& g, hipStream_t stream) {
+// rows of a super-panel (tile_mn): TSTAR_GEMM_GM overrides the default for A/B runs (1 = the panel-major order of rounds 1-3)
+static int default_group_m() {
+    static const int gm = [] { const char* e = getenv("TSTAR_GEMM_GM"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    return gm;
+}
+
+int gemm_f32(const GemmArgs& g0, hipStream_t stream) {
+    GemmArgs g = g0;
+    if (g.group_m <= 0) g.group_m = default_group_m();
     TSTAR_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_f32: empty problem");
     TSTAR_REQUIRE(g.N % 128 == 0, "gemm_f32: N must be a multiple of 128");
     TSTAR_REQUIRE(g.K % BK == 0, "gemm_f32: K must be a multiple of 32");

@@ -20,6 +20,7 @@ struct GemmArgs {
     int patch_np;        // patches per image (576) for the patch-embed epilogue
     int tile_cfg;        // -1 auto; 0 = 128x128, 1 = 64x128, 2 = 64x64 block tile, 3 = hybrid 128x128 + 64x128 tail (half/half); 16 + n = hybrid with n big row tiles (diagnostic)
     int m_split;         // hybrid launch: rows [0, m_split) use 128-row tiles (set by the launcher)
+    int group_m;         // row panels per super-panel of the tile order (gemm_f32.hip tile_mn); 0 = the library's default
     int a_terms;         // bf16-weight tile (Wb set): 2 = activations as two round-to-nearest bf16 terms (2 MFMA
                          // products per algorithmic product); anything else = the exact three-term split
 };
