@@ -163,6 +163,146 @@ __global__ __launch_bounds__(256, MINW) void gemm_frag(const float* __restrict__
     }
 }
 
+// Two-term bf16-weight tile, HYBRID W path: of a wave's 4 column tiles NL come through LDS (staged from the fragment-packed
+// copy: a fragment is 1 KB contiguous, read back linearly) and 4 - NL straight from global memory.  The all-LDS tile is
+// LDS-bound (96 KB per 1024 matrix-pipe cycles), the all-global one vector-memory-bound; this splits the W bytes between the paths.
+template <int NL, int D>
+__global__ __launch_bounds__(256, 2) void gemm_w2_hybrid(const float* __restrict__ A, const char* __restrict__ Wp,
+                                                         float* __restrict__ C, int M, int N, int K) {
+    constexpr int TM = 2, TN = 4, NG = TN - NL, BM = 128, BN = 256, BK = 32, NAT = 2;
+    constexpr int A_T = BM * 64, W_T = 2 * NL * 2 * 1024;                 // W region per buffer: wn (2) x NL tiles x 2 k-steps x 1 KB
+    constexpr int BUF = NAT * A_T + W_T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt = N / BN, mt = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    constexpr int NA = BM / 32;
+    const int c4 = t & 7, r0 = t >> 3;
+    const float* ap[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { int ar = m0 + r0 + 32 * i; ar = ar < M ? ar : M - 1; ap[i] = A + (size_t)ar * K + c4 * 4; }
+    const int nph = K / 16;                                               // KB per n-tile stream (one plane)
+    // global tiles of this wave: j = NL .. TN-1
+    const char* wg[NG > 0 ? NG : 1];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) wg[j] = Wp + (size_t)((n0 >> 5) + wn * TN + NL + j) * nph * 1024 + lane * 16;
+    // LDS staging of the NL tiles of both wn: 2 * NL * 2 fragments of 1 KB per K tile = 4 NL KB = NL * 256 threads x 16 B
+    // chunk c (16 B): frag = c / 64 -> (wn_ = frag / (NL * 2), jl = (frag / 2) % NL, s = frag % 2), lane_ = c % 64
+    const char* wl[NL > 0 ? NL : 1];
+#pragma unroll
+    for (int p = 0; p < NL; ++p) {
+        const int c = t + 256 * p, frag = c >> 6, ln = c & 63;
+        const int wn_ = frag / (NL * 2), jl = (frag >> 1) % NL, s = frag & 1;
+        wl[p] = Wp + ((size_t)((n0 >> 5) + wn_ * TN + jl) * nph + s) * 1024 + ln * 16;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[NA];
+    u32x4 rw[NL > 0 ? NL : 1];
+    u32x4 ring[D][NG > 0 ? NG : 1];
+    auto gload = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+#pragma unroll
+        for (int p = 0; p < NL; ++p) rw[p] = *reinterpret_cast<const u32x4*>(wl[p] + (size_t)kt * 2048);
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            u32x2 sp[NAT];
+            split4_rn<NAT>(ra[i], sp);
+            const int off = lds_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
+        }
+#pragma unroll
+        for (int p = 0; p < NL; ++p) *reinterpret_cast<u32x4*>(base + NAT * A_T + (t + 256 * p) * 16) = rw[p];
+    };
+    auto wload = [&](auto SET, int q) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value;
+        q = q < nph ? q : nph - 1;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) ring[st][j] = *reinterpret_cast<const u32x4*>(wg[j] + (size_t)q * 1024);
+    };
+    const int nk = K / BK;
+    gload(0);
+    if constexpr (D > 1) wload(std::integral_constant<int, 0>{}, 0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        const char* base = smem + (kt & 1) * BUF;
+        __builtin_amdgcn_s_setprio(1);
+        [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int s = P;
+                if constexpr (NG > 0) wload(std::integral_constant<int, (P + D - 1) % D>{}, kt * 2 + P + D - 1);
+                bf16x8 fa[NAT][TM], fw[NL > 0 ? NL : 1];
+#pragma unroll
+                for (int k = 0; k < NAT; ++k)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[k][i] = *reinterpret_cast<const bf16x8*>(base + k * A_T + lds_off(wm * TM * 32 + i * 32 + l31, 2 * s + h));
+#pragma unroll
+                for (int j = 0; j < NL; ++j)
+                    fw[j] = *reinterpret_cast<const bf16x8*>(base + NAT * A_T + (((wn * NL + j) * 2 + s) * 64 + lane) * 16);
+#pragma unroll
+                for (int ka = NAT - 1; ka >= 0; --ka)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ka][i], fw[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < NG; ++j)
+                            acc[i][NL + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ka][i], __builtin_bit_cast(bf16x8, ring[P % D][j]), acc[i][NL + j], 0, 0, 0);
+                    }
+            }(), ...);
+        }(std::make_integer_sequence<int, 2>{});
+        __builtin_amdgcn_s_setprio(0);
+        if (more) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+template <int NL, int D>
+float launch_h(const float* A, const char* Wp, float* C, int M, int N, int K, int iters) {
+    const int lds = 2 * (2 * 128 * 64 + 2 * NL * 2 * 1024);
+    auto k = gemm_w2_hybrid<NL, D>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int nwg = ((M + 127) / 128) * (N / 256);
+    if (iters == 0) { hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K); CK(hipDeviceSynchronize()); return 0.f; }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
 // native f32 MFMA, one wave per 32x32 tile, k in order (error reference only)
 __global__ void gemm_native_f32(const float* A, const float* W, float* C, int M, int N, int K) {
     const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
@@ -281,6 +421,21 @@ int main(int argc, char** argv) {
                2.0 * M * N * K / ms / 1e9, np * 2.0 * M * N * K / ms / 1e9);
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "hybrid")) {
+        struct Shape { int N, K; } shapes[] = {{768, 768}, {2304, 768}, {3072, 768}, {768, 3072}};
+        std::vector<unsigned short> pk;
+        for (auto sh : shapes) {
+            const double fl = 2.0 * M * sh.N * sh.K;
+            pack_w(hW.data(), sh.N, sh.K, 1, true, pk); CK(hipMemcpy(Wp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+            auto pr = [&](const char* nm, float ms) { printf("N=%4d K=%4d %-44s %7.3f ms  %6.1f TFLOP/s algorithmic  %6.0f executed\n", sh.N, sh.K, nm, ms, fl / ms / 1e9, 2 * fl / ms / 1e9); fflush(stdout); };
+            pr("two-term, all W global (D2)", launch<2, 4, 2, 1, 1, 2, 2>(A, Wp, C, M, sh.N, sh.K, 5));
+            pr("two-term hybrid NL=4 (all W via LDS, packed)", launch_h<4, 1>(A, Wp, C, M, sh.N, sh.K, 5));
+            pr("two-term hybrid NL=3 D2", launch_h<3, 2>(A, Wp, C, M, sh.N, sh.K, 5));
+            pr("two-term hybrid NL=2 D2", launch_h<2, 2>(A, Wp, C, M, sh.N, sh.K, 5));
+            pr("two-term hybrid NL=1 D2", launch_h<1, 2>(A, Wp, C, M, sh.N, sh.K, 5));
+        }
+        return 0;
+    }
     // ---- register-only MFMA rates on random operands
     {
         std::vector<unsigned short> fr(8 * 64 * 8);
@@ -356,6 +511,8 @@ int main(int argc, char** argv) {
         pack_w(w.data(), n, k, 1, true, pk); CK(hipMemcpy(Wp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
         launch<2, 4, 2, 1, 1, 2, 2>(a2, Wp, C, m, n, k, 0); report("bf16 W, 2-term A (vs bf16 W)", refb);
         launch<2, 4, 3, 1, 2, 1, 2>(a2, Wp, C, m, n, k, 0); report("bf16 W, 3-term A (vs bf16 W)", refb);
+        launch_h<2, 2>(a2, Wp, C, m, n, k, 0); report("bf16 W, 2-term, hybrid NL=2", refb);
+        launch_h<4, 1>(a2, Wp, C, m, n, k, 0); report("bf16 W, 2-term, hybrid NL=4", refb);
         CK(hipFree(a2));
     }
 
@@ -381,6 +538,10 @@ int main(int argc, char** argv) {
         pr("bf16W 2-term 128x256 D1 2blk", launch<2, 4, 2, 1, 1, 1, 2>(A, Wp, C, M, sh.N, sh.K, 5), 2);
         if (!quick) pr("bf16W 2-term 256x128 D2 (4x2)", launch<4, 2, 2, 1, 1, 2, 2>(A, Wp, C, M, sh.N, sh.K, 5), 2);
         pr("bf16W 3-term 128x256 D2 2blk", launch<2, 4, 3, 1, 2, 2, 2>(A, Wp, C, M, sh.N, sh.K, 5), 3);
+        pr("bf16W 2-term hybrid NL=4 (all W via LDS)", launch_h<4, 1>(A, Wp, C, M, sh.N, sh.K, 5), 2);
+        pr("bf16W 2-term hybrid NL=3 D2", launch_h<3, 2>(A, Wp, C, M, sh.N, sh.K, 5), 2);
+        pr("bf16W 2-term hybrid NL=2 D2", launch_h<2, 2>(A, Wp, C, M, sh.N, sh.K, 5), 2);
+        pr("bf16W 2-term hybrid NL=1 D2", launch_h<1, 2>(A, Wp, C, M, sh.N, sh.K, 5), 2);
         printf("\n");
     }
     return 0;

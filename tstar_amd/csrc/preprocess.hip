@@ -21,6 +21,7 @@
 //    (:187-188).  cv2 is not importable in the build container: this bilinear
 //    is the build's own definition ("parity unpinned").
 #include "common.h"
+#include <string.h>
 #include "heads.h"
 #include <math.h>
 #include <map>
@@ -298,7 +299,19 @@ static int get_fused(int kind, int src, int mid, int dst, int pitch, const uint4
         auto it = g_fused.find(key2);
         if (it == g_fused.end()) {
             std::vector<uint4> h;
-            if (kind == 0 || kind == 1) {
+            if (kind == 8) {
+                // X table of a single resize as THREE ARRAYS (off[], sel[], w[], each padded to a multiple of 4 entries): a lane
+                // of the 4-pixel kernel reads its four consecutive entries of one field as ONE 16-byte load, and the 64 lanes of a
+                // wave read 1 KB contiguously.  The array-of-uint4 layout (kind 0) made each of a lane's four entry loads touch
+                // a different 64-byte line per lane -- 64 lines per wave instruction, 256 per four pixels: two thirds of the
+                // kernel's time on the vector-memory path (round 4)
+                build(src, dst, h1);
+                const int np = (dst + 3) / 4 * 4;
+                std::vector<unsigned> a(3 * (size_t)np, 0u);
+                for (int d = 0; d < dst; ++d) { unsigned o, sl, w; fused_x_sample(h1[d], src, &o, &sl, &w); a[d] = o; a[np + d] = sl; a[2 * np + d] = w; }
+                h.resize(a.size() / 4);
+                memcpy(h.data(), a.data(), a.size() * 4);
+            } else if (kind == 0 || kind == 1) {
                 build(src, dst, h1);
                 h.resize(dst);
                 for (int d = 0; d < dst; ++d) {
@@ -375,8 +388,17 @@ __global__ __launch_bounds__(256) void bilinear_gather_rgb_kernel(const uint8_t*
     const unsigned b0 = y.z, b1 = y.w;
     uint4 x[PX];
     uint64_t w0[PX], w1[PX];
+    if constexpr (PX == 4) {
+        // fx = three arrays of ow entries (get_fused kind 8): one coalesced 16-byte load per field
+        const unsigned* fa = reinterpret_cast<const unsigned*>(fx);
+        const uint4 xo = *reinterpret_cast<const uint4*>(fa + ox), xs = *reinterpret_cast<const uint4*>(fa + ow + ox),
+                    xw = *reinterpret_cast<const uint4*>(fa + 2 * ow + ox);
+        x[0] = make_uint4(xo.x, xs.x, xw.x, 0); x[1 % PX] = make_uint4(xo.y, xs.y, xw.y, 0);
+        x[2 % PX] = make_uint4(xo.z, xs.z, xw.z, 0); x[3 % PX] = make_uint4(xo.w, xs.w, xw.w, 0);
+    } else {
 #pragma unroll
-    for (int k = 0; k < PX; ++k) x[k] = fx[ox + k];
+        for (int k = 0; k < PX; ++k) x[k] = fx[ox + k];
+    }
 #pragma unroll
     for (int k = 0; k < PX; ++k) { w0[k] = load_window(f + (size_t)(y.x + x[k].x)); w1[k] = load_window(f + (size_t)(y.y + x[k].x)); }
     unsigned v[PX][3];
@@ -712,10 +734,10 @@ int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int
     rc = get_lintab(H, oh, &ty); if (rc) return rc;
     if (!nv12 && n <= 65535 && rgb_fast_ok(W, (long long)ow * oh, ow) && (size_t)H * W * 3 < (1ull << 31)) {
         const uint4 *fx, *fy;
-        rc = get_fused(0, W, 0, ow, 3 * W, &fx); if (rc) return rc;
-        rc = get_fused(1, H, 0, oh, 3 * W, &fy); if (rc) return rc;
         // 4 pixels per lane need dword-aligned 12-byte stores: a row of the output must be a multiple of 4 pixels
         const int px = (ow % 4 == 0 && ow >= 8 && (reinterpret_cast<size_t>(out) & 3) == 0) ? 4 : 1;   // ow / px >= 2 (magic_of)
+        rc = get_fused(px == 4 ? 8 : 0, W, 0, ow, 3 * W, &fx); if (rc) return rc;
+        rc = get_fused(1, H, 0, oh, 3 * W, &fy); if (rc) return rc;
         const int owq = ow / px, nunits = owq * oh;
         const dim3 g((unsigned)((nunits + 255) / 256), (unsigned)n);
         if (px == 4) hipLaunchKernelGGL(bilinear_gather_rgb_kernel<4>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);

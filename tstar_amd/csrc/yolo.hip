@@ -438,7 +438,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(P == 8 ? 2 
 constexpr int HLD = SWK + 4;
 template <int TH, int TW, bool XROW> struct HaloGeom {
     static constexpr int HW2 = TW + 2, NROW = TH + 2 + (XROW ? 1 : 0), NP = NROW * HW2, P = TH * TW / 64;
-    static constexpr int NDMA = (NP * 5 + 63) / 64, NIT = (NDMA + 3) / 4, SLOTS = NDMA * 64 / 5 + 1;
+    // LDS row pitch: HW2 pixels of 5 quads (4 data + 1 pad) plus 6 pad quads = 96 B.  A lane group of a ds_read_b128 covers 16
+    // CONSECUTIVE patch pixels, which wrap from one patch row into the next (TW = 40 or 20 pixels per row); 16 pixels at 80 B
+    // cover the 64 banks exactly once only if pixel 0 of the next row sits where pixel TW of this row would, i.e. the pitch is
+    // TW * 80 B modulo the 256-B bank period: (TW + 2) * 80 + 96 (round 3 measured SQ_LDS_BANK_CONFLICT / SQ_BUSY_CYCLES = 0.51
+    // on this kernel with the unpadded rows: every group that straddled two rows collided on two banks)
+    static constexpr int RQ = HW2 * 5 + 6, RPF = RQ * 4;
+    static constexpr int NDMA = (NROW * RQ + 63) / 64, NIT = (NDMA + 3) / 4, LDSF = NDMA * 256 + HLD;
     static_assert(TH * TW % 64 == 0, "a halo patch is a whole number of pixels per lane");
 };
 template <int N> struct WRow;
@@ -449,7 +455,8 @@ template <int TH, int TW, int NCH, bool XROW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 16 ? 3 : 4, NCH == 16 ? 3 : 4))) void conv_halo_kernel(ConvArgs a, int mt, int nt) {
     using G = HaloGeom<TH, TW, XROW>;
     constexpr int HW2 = G::HW2, HP = G::P, NIT = G::NIT, NDMA = G::NDMA, NC2 = NCH / 2;
-    __shared__ __attribute__((aligned(16))) float Hs[G::SLOTS][HLD];
+    constexpr int RQ = G::RQ, RPF = G::RPF;
+    __shared__ __attribute__((aligned(16))) float Hs[G::LDSF];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = xcd_remap(blockIdx.x, mt * nt);
@@ -467,16 +474,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 16 ?
     }
     const bool nb = XROW && rb < TH;
     const int last = TH + 1 + (nb ? 1 : 0);                           // LDS row of the bottom halo
-    // staging roles: DMA instruction i = wave + 4 it fills halo slots 64 i .. 64 i + 63; slot s = halo pixel s / 5, quad s % 5
+    // staging roles: DMA instruction i = wave + 4 it fills LDS quads 64 i .. 64 i + 63; quad s = halo row s / RQ, and inside the row
+    // pixel (s % RQ) / 5, quad (s % RQ) % 5 (quad 4 of a pixel and the six quads behind the last pixel are padding)
     unsigned hoff[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int sidx = (wave + 4 * it) * 64 + lane;
-        const int hp = sidx / 5, q = sidx - hp * 5;
-        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const int hy = sidx / RQ, rem = sidx - hy * RQ;
+        const int hx = rem / 5, q = rem - hx * 5;
         const int sr = row0 + hy - 1 - ((nb && hy > rb + 1) ? 1 : 0);  // stacked source row of LDS row hy
         const int ix = x0 + hx - 1;
-        bool ok = hp < G::NP && q < 4 && hy <= last && ix >= 0 && ix < a.W && sr >= 0 && sr < rows_total;
+        bool ok = hy < G::NROW && hx < HW2 && q < 4 && hy <= last && ix >= 0 && ix < a.W && sr >= 0 && sr < rows_total;
         if (nb && hy == rb + 1) ok = false;                            // the zero row between two images
         if (hy == 0 && row0 % a.H == 0) ok = false;                    // top halo above an image's first row
         if (hy == last && (row0 + TH) % a.H == 0) ok = false;          // bottom halo below an image's last row
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 16 ?
         for (int it = 0; it < NIT; ++it) {
             if (wave + 4 * it < NDMA) {                                    // wave-uniform
                 const unsigned off = hoff[it] == 0xffffffffu ? zoffb : hoff[it] + 4u * (unsigned)ci0;
-                const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)&Hs[0][0]) + (unsigned)(wave + 4 * it) * 1024u;
+                const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr)&Hs[0]) + (unsigned)(wave + 4 * it) * 1024u;
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(a.src), "s"(la) : "memory");
             }
         }
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 16 ?
 #pragma unroll
     for (int j = 0; j < HP; ++j) {
         const int p = lane + 64 * j, r = p / TW, c = p - r * TW;
-        hb[j] = ((r + ((nb && r >= rb) ? 1 : 0)) * HW2 + c) * HLD;
+        hb[j] = (r + ((nb && r >= rb) ? 1 : 0)) * RPF + c * HLD;
     }
     f32x2 acc[HP][NC2];
 #pragma unroll
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 16 ?
     typedef typename WRow<NCH>::T wrow_t;
     typedef __attribute__((address_space(4))) const wrow_t cwrow;
     const float* wcol = a.wt + (active ? cg0 : 0);
-    const float* hs = &Hs[0][0];
+    const float* hs = &Hs[0];
 
     for (int ci0 = 0; ci0 < a.cin; ci0 += SWK) {
         __syncthreads();                                                    // everybody is done with the previous slice's patch
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 16 ?
         if (!active) continue;
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int toff = (ky * HW2 + kx) * HLD;                         // floats
+            const int toff = ky * RPF + kx * HLD;                            // floats
             const float* wrow0 = wcol + (size_t)(tap * a.cin + ci0) * a.cout;
             wrow_t wna = *(cwrow*)(unsigned long long)(wrow0);
             wrow_t wnb = *(cwrow*)(unsigned long long)(wrow0 + a.cout);
