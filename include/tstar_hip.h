@@ -310,6 +310,10 @@ int tstar_gemm_bf16w_pre(const float* d_A, const void* d_Wb, float* d_C, const f
  * (TSTAR_WEIGHTS_F32X3); N % 128 == 0, K % 32 == 0; tile_cfg as above, 4 forces the 128x256 tile, 5 forbids it; synchronises */
 int tstar_gemm_f32x3(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                      int M, int N, int K, int act, int tile_cfg, void* stream);
+/* the same in two steps for microbenchmarks: pack once (d_Wp: 6 * N * K bytes on the device), then enqueue-only GEMMs on the packed planes */
+int tstar_pack_f32x3(const float* d_W, void* d_Wp, int N, int K, void* stream);
+int tstar_gemm_f32x3_pre(const float* d_A, const void* d_Wp, float* d_C, const float* d_bias, const float* d_residual,
+                         int M, int N, int K, int act, int tile_cfg, void* stream);
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream);
 /* qkv [B*T, 3*heads*64] -> out [B*T, heads*64]; mode 0 full, 1 causal + key mask u8 [B,T] */
 int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int heads, int mode,

@@ -1,6 +1,6 @@
 """bf16-weight GEMM tiles on the bench's shapes: exact three-term split vs two-term, narrow tiles vs the 128x256 tile.
 
-    python tools/bench_gemm_bf16.py [B ...]     # TFLOP/s algorithmic (2MNK / time); executed = x3 (three-term) or x2 (two-term)
+    python tools/bench_gemm_bf16.py [B ...]     # TFLOP/s algorithmic (2MNK / time); executed = x3 (three-term), x2 (two-term), x6 (f32x3)
 """
 import os
 import sys
@@ -34,6 +34,17 @@ for B in Bs:
         b = torch.randn(N, device="cuda")
         C = torch.zeros(M, N, device="cuda")
         row = {}
+        # round 4: the f32x3 mode (f32 weights as three exact bf16 planes, six products) and the native f32 tile on the same shape
+        Wf = torch.randn(N, K, device="cuda") * K ** -0.5
+        Wp = torch.empty(N * K * 6, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.tstar_pack_f32x3(Wf.data_ptr(), Wp.data_ptr(), N, K, s))
+        for _ in range(2):
+            ms = timeit(lambda: _lib.check(lib.tstar_gemm_f32x3_pre(A.data_ptr(), Wp.data_ptr(), C.data_ptr(), b.data_ptr(),
+                                                                    C.data_ptr() if res else None, M, N, K, 0, -1, s)))
+            row["f32x3"] = max(row.get("f32x3", 0.0), 2.0 * M * N * K / ms / 1e9)
+            ms = timeit(lambda: _lib.check(lib.tstar_gemm_f32_cfg(A.data_ptr(), Wf.data_ptr(), C.data_ptr(), b.data_ptr(),
+                                                                  C.data_ptr() if res else None, M, N, K, 0, -1, s)))
+            row["native f32"] = max(row.get("native f32", 0.0), 2.0 * M * N * K / ms / 1e9)
         for _ in range(2):
             for name, terms, cfg in variants:
                 ms = timeit(lambda: _lib.check(lib.tstar_gemm_bf16w_pre(A.data_ptr(), Wb.data_ptr(), C.data_ptr(), b.data_ptr(),

@@ -15,13 +15,14 @@ PY="python $ROOT/bench.py"
 # 1. the secondary workloads (the bench line itself runs last, after the counter passes, so that its
 #    roofline.traffic field is this collection's figure)
 : > "$OUT/bench.err"
-$PY --steps 32 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights bf16_exact --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline > "$OUT/${TAG}_bench_config5_exact_split.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --workload haystack --no-cpu-baseline > "$OUT/${TAG}_bench_haystack_1gpu.json" 2>> "$OUT/bench.err"
-$PY --workload haystack32 --no-cpu-baseline > "$OUT/${TAG}_bench_haystack32_1gpu.json" 2>> "$OUT/bench.err"
+$PY --steps 32 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights f32x3 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_f32x3.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16_exact --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_config5_exact_split.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --workload haystack --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_haystack_1gpu.json" 2>> "$OUT/bench.err"
+$PY --workload haystack32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_haystack32_1gpu.json" 2>> "$OUT/bench.err"
 
 # 1b. YOLO-World backend: its own script (bench line, kernel trace, per-shape and per-layer tables, counters)
 bash $ROOT/tools/collect_yolo_profiles.sh $TAG
@@ -31,7 +32,7 @@ cd /tmp
 #    verification, config.grid4 -- run too; the timed region is cut out of the trace at the marker kernels bench.py
 #    enqueues around it, tools/rocpd_window.py)
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $PY --steps 8 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/rocprof_kt.err"
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $PY --steps 8 --warmup 1 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/rocprof_kt.err"
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 BJ="$OUT/${TAG}_bench_under_rocprofv3.json"
 python $ROOT/tools/rocpd_stats.py "$DB" > "$OUT/${TAG}_rocprofv3_kernel_stats.md"
@@ -49,7 +50,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_IN
     rm -rf /tmp/prof_$N
     # --no-grid4 --no-verify: every GEMM dispatch of the run is one of the timed steps' (plus the text tower's 48 tiny ones),
     # so the per-launch averages are over the same population as the bench line's avg_launch_gflop
-    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify > /dev/null 2> "$OUT/rocprof_$N.err"
+    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify --no-other-configs > /dev/null 2> "$OUT/rocprof_$N.err"
 done
 F=$(find /tmp/prof_FETCH_SIZE -name '*.db' | head -1)
 W=$(find /tmp/prof_WRITE_SIZE -name '*.db' | head -1)

@@ -71,6 +71,8 @@ SIGNATURES = {
     "tstar_gemm_bf16w2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tstar_gemm_bf16w_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tstar_gemm_f32x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tstar_pack_f32x3": (_i, [_vp, _vp, _i, _i, _vp]),
+    "tstar_gemm_f32x3_pre": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tstar_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tstar_draw_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "tstar_attention_split": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -671,6 +671,21 @@ int tstar_gemm_f32x3(const float* d_A, const float* d_W, float* d_C, const float
     return rc;
 }
 
+int tstar_pack_f32x3(const float* d_W, void* d_Wp, int N, int K, void* stream) {
+    TSTAR_REQUIRE(d_W && d_Wp, "tstar_pack_f32x3: null argument");
+    TSTAR_REQUIRE(N > 0 && K > 0, "tstar_pack_f32x3: empty matrix");
+    return pack_weights_x3(d_W, d_Wp, N, K, (hipStream_t)stream);
+}
+
+int tstar_gemm_f32x3_pre(const float* d_A, const void* d_Wp, float* d_C, const float* d_bias, const float* d_residual, int M, int N,
+                         int K, int act, int tile_cfg, void* stream) {
+    TSTAR_REQUIRE(d_A && d_Wp && d_C, "tstar_gemm_f32x3_pre: null argument");
+    GemmArgs g = mk_gemm(nullptr, d_A, reinterpret_cast<const float*>(d_Wp), d_C, d_bias, d_residual, M, N, K, K, N, act);
+    g.Wp = d_Wp;
+    g.tile_cfg = tile_cfg;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+
 int tstar_layernorm_f32(const float* d_x, float* d_y, const float* d_w, const float* d_b, int rows, int D, void* stream) {
     TSTAR_REQUIRE(d_x && d_y && d_w && d_b, "tstar_layernorm_f32: null argument");
     return layernorm_f32(d_x, d_y, d_w, d_b, rows, D, (hipStream_t)stream);
