@@ -164,6 +164,130 @@ __global__ __launch_bounds__(256, MINW) void gemm_frag(const float* __restrict__
 }
 
 template <int TM, int TN, int NAT, int NWT, int MAXSUM, int D, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_frag3(const float* __restrict__ A, const char* __restrict__ Wp,
+                                                       float* __restrict__ C, int M, int N, int K) {
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, BK = 32, NS = BK / 16, PPT = NS * NWT;
+    static_assert(PPT % D == 0, "ring depth must divide the phases of a K tile");
+    constexpr int A_T = BM * 64, BUF = NAT * A_T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt = N / BN, mt = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    constexpr int NA = BM / 32;
+    const int c4 = t & 7, r0 = t >> 3;
+    const float* ap[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { int ar = m0 + r0 + 32 * i; ar = ar < M ? ar : M - 1; ap[i] = A + (size_t)ar * K + c4 * 4; }
+    // W fragment streams: n-tile j of this wave = (n0 + wn * TN * 32) / 32 + j; stream of nph KB
+    const int nph = (K / 16) * NWT;
+    const char* wb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wb[j] = Wp + (size_t)((n0 >> 5) + wn * TN + j) * nph * 1024 + lane * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NA];
+    u32x4 ring[D][TN];
+    auto gloadA = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+    };
+    auto lstore_part = [&](int buf, auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        char* base = smem + buf * BUF;
+        {
+            u32x2 sp[NAT];
+            split4_rn<NAT>(ra[i], sp);
+            const int off = lds_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            u32x2 sp[NAT];
+            split4_rn<NAT>(ra[i], sp);
+            const int off = lds_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < NAT; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
+        }
+    };
+    auto wload = [&](auto SET, int q) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value;
+        q = q < nph ? q : nph - 1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) ring[st][j] = *reinterpret_cast<const u32x4*>(wb[j] + (size_t)q * 1024);
+    };
+    const int nk = K / BK;
+    gloadA(0);
+    // ring prologue: phases 0 .. D-2
+    [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
+        (wload(std::integral_constant<int, Q>{}, Q), ...);
+    }(std::make_integer_sequence<int, D - 1>{});
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gloadA(kt + 1);
+        const char* base = smem + (kt & 1) * BUF;
+        __builtin_amdgcn_s_setprio(1);
+        bf16x8 fa[NAT][TM];
+        [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int s = P / NWT, ph = P % NWT, kw = NWT - 1 - ph;
+                // refill the ring D-1 phases ahead
+                wload(std::integral_constant<int, (P + D - 1) % D>{}, kt * PPT + P + D - 1);
+                if constexpr (ph == 0) {
+#pragma unroll
+                    for (int k = 0; k < NAT; ++k)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            fa[k][i] = *reinterpret_cast<const bf16x8*>(base + k * A_T + lds_off(wm * TM * 32 + i * 32 + l31, 2 * s + h));
+                }
+#pragma unroll
+                for (int ka = NAT - 1; ka >= 0; --ka) {
+                    if (ka + kw > MAXSUM) continue;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ka][i], __builtin_bit_cast(bf16x8, ring[P % D][j]), acc[i][j], 0, 0, 0);
+                }
+                // the split + LDS store of the NEXT tile's activations, one f32x4 per phase from phase PPT - NA on: VALU / DS work that
+                // issues in the shadow of this phase's MFMAs instead of after the last one
+                if constexpr (P >= PPT - NA) { if (more) lstore_part((kt + 1) & 1, std::integral_constant<int, P - (PPT - NA)>{}); }
+            }(), ...);
+        }(std::make_integer_sequence<int, PPT>{});
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int NAT, int NWT, int MAXSUM, int D, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm_frag2(const float* __restrict__ A, const char* __restrict__ Wp,
                                                        float* __restrict__ C, int M, int N, int K) {
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, BK = 32, NS = BK / 16, PPT = NS * NWT;
@@ -409,6 +533,24 @@ __global__ __launch_bounds__(256, 2) void gemm_w2_hybrid(const float* __restrict
 }
 
 template <int TM, int TN, int NAT, int NWT, int MAXSUM, int D, int MINW>
+float launch3(const float* A, const char* Wp, float* C, int M, int N, int K, int iters) {
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+    static_assert(BM / 32 <= 2 * NWT, "one lstore part per phase");
+    const int lds = 2 * NAT * BM * 64;
+    auto k = gemm_frag3<TM, TN, NAT, NWT, MAXSUM, D, MINW>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int nwg = ((M + BM - 1) / BM) * (N / BN);
+    if (iters == 0) { hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K); CK(hipDeviceSynchronize()); return 0.f; }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+template <int TM, int TN, int NAT, int NWT, int MAXSUM, int D, int MINW>
 float launch2(const float* A, const char* Wp, float* C, int M, int N, int K, int iters) {
     constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
     const int lds = 2 * NAT * BM * 64;
@@ -568,9 +710,9 @@ int main(int argc, char** argv) {
             auto pr = [&](const char* nm, float ms) { printf("N=%4d K=%4d %-44s %7.3f ms  %6.1f TFLOP/s algorithmic\n", sh.N, sh.K, nm, ms, fl / ms / 1e9); fflush(stdout); };
             for (int rep = 0; rep < 2; ++rep) {
                 pr("x6 128x256, A prefetch 1 tile", launch<2, 4, 3, 3, 2, 3, 2>(A, Wp, C, M, sh.N, sh.K, 5));
-                pr("x6 128x256, A prefetch 2 tiles", launch2<2, 4, 3, 3, 2, 3, 2>(A, Wp, C, M, sh.N, sh.K, 5));
+                pr("x6 128x256, lstore interleaved", launch3<2, 4, 3, 3, 2, 3, 2>(A, Wp, C, M, sh.N, sh.K, 5));
                 pr("x6 128x128, A prefetch 1 tile", launch<2, 2, 3, 3, 2, 3, 2>(A, Wp, C, M, sh.N, sh.K, 5));
-                pr("x6 128x128, A prefetch 2 tiles", launch2<2, 2, 3, 3, 2, 3, 2>(A, Wp, C, M, sh.N, sh.K, 5));
+                pr("x6 128x128, lstore interleaved", launch3<2, 2, 3, 3, 2, 3, 2>(A, Wp, C, M, sh.N, sh.K, 5));
             }
         }
         return 0;
