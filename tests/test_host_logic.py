@@ -576,3 +576,26 @@ def test_native_curfit_bit_identical_to_scipy(golden_dir):
              else np.linspace(0.1, 0.4, m) + 1e-6 * rs.standard_normal(m))
         s = float(rs.choice([0.5, 0.5, 0.05, 5.0, 1e-4]))
         check(x, y, s, f"random {trial} m={m} s={s}")
+
+
+def test_spline_worker_count_follows_the_affinity_mask(monkeypatch):
+    """Round-3 review item 7: the FITPACK workers of a rank are sized from the hardware threads the process may run on, and
+    the node total stays within half of them whether the mask is the whole host (divided by LOCAL_WORLD_SIZE), a container's
+    cpuset shared by the ranks (divided too) or a per-rank cpuset (taken as the rank's share)."""
+    from tstar_amd import spline_pool as SP
+
+    def workers(mask, cpus, ranks):
+        monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(mask)))
+        monkeypatch.setattr(os, "cpu_count", lambda: cpus)
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(ranks))
+        monkeypatch.delenv("TSTAR_SPLINE_WORKERS", raising=False)
+        return SP.default_workers()
+
+    assert workers(256, 256, 1) == 16 and workers(256, 256, 8) == 16        # whole host: 256 / 8 / 2 = 16
+    assert workers(32, 256, 8) == 16                                          # per-rank cpuset of 32 threads: the rank's own share
+    assert workers(64, 256, 8) == 4                                           # a 64-thread container shared by 8 ranks: 64 / 8 / 2
+    assert workers(8, 8, 2) == 2 and workers(2, 2, 8) == 1
+    for mask, cpus, ranks in ((256, 256, 8), (64, 256, 8), (8, 8, 2), (128, 128, 4)):
+        assert workers(mask, cpus, ranks) * ranks <= max(ranks, mask // 2)
+    monkeypatch.setenv("TSTAR_SPLINE_WORKERS", "3")
+    assert SP.default_workers() == 3

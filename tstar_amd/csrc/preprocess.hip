@@ -303,8 +303,8 @@ static int get_fused(int kind, int src, int mid, int dst, int pitch, const uint4
                 // X table of a single resize as THREE ARRAYS (off[], sel[], w[], each padded to a multiple of 4 entries): a lane
                 // of the 4-pixel kernel reads its four consecutive entries of one field as ONE 16-byte load, and the 64 lanes of a
                 // wave read 1 KB contiguously.  The array-of-uint4 layout (kind 0) made each of a lane's four entry loads touch
-                // a different 64-byte line per lane -- 64 lines per wave instruction, 256 per four pixels: two thirds of the
-                // kernel's time on the vector-memory path (round 4)
+                // a different 64-byte line per lane -- 64 lines per wave instruction, 256 per four pixels (round 4: 91.6 -> 74.0 us
+                // for 180 verification frames, 2.37 -> 2.93 TB/s)
                 build(src, dst, h1);
                 const int np = (dst + 3) / 4 * 4;
                 std::vector<unsigned> a(3 * (size_t)np, 0u);

@@ -39,16 +39,17 @@ def host_threads() -> int:
 
 
 def default_workers() -> int:
-    """TSTAR_SPLINE_WORKERS, else up to 16 workers out of half this rank's share of the host threads it may use.  When the
-    launcher has pinned each rank to its own cpuset the affinity mask already IS the rank's share; otherwise the mask is the
-    whole host and is divided by LOCAL_WORLD_SIZE -- so the node total stays <= half the usable threads either way."""
+    """TSTAR_SPLINE_WORKERS, else up to 16 workers out of half this rank's share of the host threads it may use.  The affinity
+    mask is either the rank's own cpuset (a launcher that pins ranks: the mask is about machine / ranks wide and IS the share) or
+    a set all local ranks run on (the whole host, or a container's cpuset: then it is divided by LOCAL_WORLD_SIZE) -- told apart by
+    its width, so the node total stays <= half the usable threads either way."""
     env = os.environ.get("TSTAR_SPLINE_WORKERS")
     if env is not None:
         return max(0, int(env))
     ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     usable = host_threads()
-    pinned = usable < (os.cpu_count() or usable)            # a narrower mask than the machine: assume it is per rank
-    share = usable if pinned and ranks > 1 else usable // ranks
+    per_rank_mask = ranks > 1 and usable * ranks <= 1.5 * (os.cpu_count() or usable)
+    share = usable if per_rank_mask else usable // ranks
     return max(1, min(16, share // 2))
 
 
