@@ -7,7 +7,9 @@ sampled seconds coincide, the first diverging iteration, the largest confidence 
 whether the keyframes are equal.  The oracle pipeline itself follows the reference end to end (goldens G9 / G9b,
 tests/test_oracle_searcher.py::test_oracle_pipeline_free_running_vs_reference_end_to_end).
 
-    python tools/l3_agreement.py [--seeds 8] [--modes f32,f32x3] > gpurun_out/l3_agreement.md      (GPU box; ~30 s of CPU per seed)
+    python tests/l3_agreement_report.py [--seeds 8] [--modes f32,f32x3] > gpurun_out/l3_agreement.md      (GPU box; ~15 s of CPU per seed)
+
+Lives under tests/ because it drives the CPU oracle (test infrastructure); tests/test_gpu_searcher.py runs a two-seed pass of it.
 """
 import argparse
 import os
@@ -27,7 +29,11 @@ def main():
     ap.add_argument("--nframes", type=int, default=3600)
     ap.add_argument("--grid", type=int, default=4)
     ap.add_argument("--budget", type=float, default=0.035, help="fraction of the frames: 0.035 * 3600 = 126 -> 8 iterations of 16")
-    args = ap.parse_args()
+    run(ap.parse_args())
+
+
+def run(args):
+    """Prints the report; returns {mode: [iterations on the oracle's trajectory, oracle iterations, searches with equal keyframes]}."""
     import torch
     torch.set_num_threads(16)
     from oracle import cpu_pipeline, searcher_ref as S
@@ -93,6 +99,7 @@ def main():
     for m in modes:
         print(f"* **{m}**: {tot[m][0]} of {tot[m][1]} iterations on the oracle's trajectory ({100.0 * tot[m][0] / max(tot[m][1], 1):.1f} %), "
               f"keyframes equal in {tot[m][2]} of {args.seeds} searches.")
+    return tot
 
 
 if __name__ == "__main__":

@@ -825,3 +825,20 @@ def test_f32x3_mode_search_teacher_forced_and_against_f32():
           f"keyframes {'equal' if tss == ts32 else 'differ'}")
     assert worst < 1e-5
     assert its == it32 and tss == ts32
+
+
+def test_l3_free_running_agreement_report(capsys):
+    """SURVEY section 7, level L3: the HIP pipeline and the CPU oracle pipeline, BOTH closed-loop from the same sampler seed
+    (tests/l3_agreement_report.py; the full 8-seed report is profiles/r04_l3_agreement.md).  Closed-loop equality is chaotic in
+    general, so the rate is reported; what is gated: every search starts on the oracle's trajectory (iteration 0 is deterministic)
+    and the confidences over the common prefix stay inside the 1e-3 contract."""
+    import types
+    import l3_agreement_report as L3
+    tot = L3.run(types.SimpleNamespace(seeds=2, modes="f32,f32x3", nframes=3600, grid=4, budget=0.014))       # 50 frames -> 4 iterations
+    out = capsys.readouterr().out
+    print(out)
+    assert set(tot) == {"f32", "f32x3"}
+    for m, (same, total, eq) in tot.items():
+        assert total == 8 and same >= 2, (m, same, total)            # at least iteration 0 of both searches
+    worst = [float(l.split("|")[6]) for l in out.splitlines() if l.startswith("| 3")]
+    assert worst and max(worst) < 1e-3
