@@ -1,13 +1,13 @@
 // Flash-style multi-head self-attention on the bf16 matrix pipe with f32-split operands, head_dim 64,
 // full (unmasked) attention only -- the vision tower's attention in the opt-in bf16-pipe modes
-// (TSTAR_WEIGHTS_BF16 / TSTAR_WEIGHTS_F32_SPLIT).  Same math as attention_f32.hip (HF modeling_owlvit.py
+// (TSTAR_WEIGHTS_BF16 / TSTAR_WEIGHTS_BF16_EXACT; the f32x3 mode keeps the exact-f32 attention).  Same math as attention_f32.hip (HF modeling_owlvit.py
 // :377-402, softmax(Q K^T / 8) V), same block/wave mapping and the same transposed-score trick; what
 // changes is the arithmetic of the two contractions:
 //
 //  * every f32 operand x is carried as two round-to-nearest bfloat16 terms x_hi + x_lo (16 significand
 //    bits, |x - x_hi - x_lo| <= 2^-18 |x|) and a product a*b runs as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on
 //    v_mfma_f32_32x32x16_bf16 (exact products, f32 accumulation, the 2^-18 lo*lo term dropped) -- the
-//    scheme of the f32-split GEMM tile (gemm_f32.hip, WMODE 2).  Per 32-key block a wave issues 24 MFMAs of
+//    two-terms-per-operand scheme of the f32-split GEMM tile of rounds 1-3 (retired in round 4).  Per 32-key block a wave issues 24 MFMAs of
 //    32 cycles instead of 64 of 64 cycles.
 //  * S^T = K Q^T: A = K tile (LDS, [key][d] bf16 planes, d contiguous), B = Q fragment (registers, split
 //    once per block, pre-scaled by log2(e)/8).
