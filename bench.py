@@ -3,6 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+(with N > 1 and no launcher around it, i.e. WORLD_SIZE unset, the command starts its own N ranks through
+torch.distributed.run on 127.0.0.1 -- self_spawn(); under the driver's launcher it is one of the ranks.)
+
 One "step" = one complete keyframe search (TStarSearcher.search(): iterative sampling, grid
 scoring, verification, distribution updates, final K=8 keyframes) over one 3600-frame
 synthetic video that is already resident in HBM -- BASELINE.json configs[1]: "Same single
@@ -371,11 +374,15 @@ def other_configs():
         "configs[1] in the f32x3 mode": ["--weights", "f32x3", "--steps", "8"],
     }
     out = {}
+    # the children are plain 1-GPU runs of their own: no launcher variables, none of this process's TSTAR_* overrides
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")
+           and not k.startswith("TSTAR_")}
     for name, flags in runs.items():
         t1 = time.perf_counter()
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--warmup", "1", "--no-cpu-baseline", "--no-grid4", "--no-other-configs"] + flags
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 out[name] = {"error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}
@@ -391,8 +398,36 @@ def other_configs():
     return out
 
 
+def self_spawn(n):
+    """`python bench.py --gpus N` typed as is (no launcher, WORLD_SIZE unset): start the N ranks ourselves -- the command the
+    driver uses, torch.distributed.run with one process per GPU on 127.0.0.1 -- and hand its exit code back; rank 0's ONE JSON
+    line goes to our stdout.  On a box with fewer than N visible GPUs the ranks share devices and the collectives go over gloo
+    (TSTAR_BENCH_BACKEND), so the command still returns a (meaningless for scaling, labelled) line instead of an error."""
+    import socket
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")        # torch.distributed.run would set 1: the host side (numpy, spline fits) is not the ranks' bottleneck but needs more than that
+    ndev = torch.cuda.device_count()
+    if ndev < n and "TSTAR_BENCH_BACKEND" not in env:
+        print(f"bench.py: {ndev} GPU(s) visible for --gpus {n}: ranks share devices, collectives over gloo", file=sys.stderr)
+        env["TSTAR_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args.gpus))
     # the searcher prints progress like the reference ("Found target ...", sampler warnings): keep stdout
     # clean for the ONE JSON line
     # ... and at the file-descriptor level too: RCCL prints a version banner and gloo its connection notes with C stdio
@@ -598,8 +633,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, frames_all, images_all = tmax[0].item(), t[1].item(), t[2].item()
+        hc = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(hc, torch.tensor([host_cpu / max(args.steps, 1)], dtype=torch.float64, device=cdev))
+        host_cpu_by_rank = [float(x.item()) for x in hc]
     else:
         frames_all, images_all = float(frames), float(images)
+        host_cpu_by_rank = [host_cpu / max(args.steps, 1)]
 
     # roofline of the dominant kernel (gemm_f32_kernel): HIP events on the launch stream, this rank
     n_l, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
@@ -698,6 +737,7 @@ def main():
                 # what predicts the 8-rank curve: CPU seconds (user + sys) of this rank's process AND its spline worker processes over
                 # the timed region, per video; host_cores = hardware threads this process may run on (its affinity mask)
                 "host_cpu_sec_per_video": host_cpu / max(args.steps, 1), "host_cpu_busy_cores": host_cpu / dt,
+                "host_cpu_sec_per_video_by_rank": host_cpu_by_rank,
                 "host_cores": _sp.host_threads(), "host_spline_workers": (len(_sp._pool) if _sp._pool is not None else 0),
                 # the per-iteration annotated grid images / frames the reference keeps unconditionally (interface_searcher.py:469-474)
                 # are NOT produced in the timed region (keep_visual_history=False); with them a search costs +2-4 %

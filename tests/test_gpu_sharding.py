@@ -168,6 +168,42 @@ def test_bench_two_ranks_equals_one_rank():
     assert "t0_boottime_ns" in one["config"]["timed_region"] and one["config"]["timed_region"]["t1_monotonic_ns"] > one["config"]["timed_region"]["t0_monotonic_ns"]
 
 
+def _launcher_free_env():
+    return {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "TSTAR_BENCH_BACKEND")}
+
+
+def test_bench_gpus2_typed_as_is_spawns_its_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (WORLD_SIZE unset) -- the way the docstring advertises the
+    command and the way a driver that reuses its N = 1 invocation would call it -- starts two ranks itself
+    (bench.self_spawn: torch.distributed.run on 127.0.0.1) and prints ONE line with n_gpus = 2.  On a 1-GPU box the
+    two ranks share the device and gather over gloo; with two or more GPUs visible the same command goes over RCCL
+    (next test)."""
+    two = _bench_line([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-grid4",
+                       "--no-verify", "--max-batch", "64"], _launcher_free_env())
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["items_total"] == 4
+    assert two["config"]["gathered_keyframe_rows"] == 4 and all(len(r) == 8 for r in two["config"]["gathered_keyframes"])
+    if torch.cuda.device_count() < 2:
+        assert two["config"]["collective_backend"] == "gloo"
+    else:
+        assert two["config"]["collective_backend"] == "nccl" and "ncclAllGather" in two["config"]["collective_path"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: real RCCL between two ranks")
+def test_bench_gpus2_over_rccl():
+    """On a multi-GPU box: the plain `python bench.py --gpus 2` command, one rank per GPU, the keyframe rows collected by
+    ONE ncclAllGather on the library's own RCCL communicator (tstar_allgather_i32) with two ranks, and the gathered rows
+    equal to a 1-rank run of the same four items."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-grid4", "--no-verify", "--max-batch", "64"]
+    two = _bench_line([sys.executable, "bench.py", "--gpus", "2"] + common, _launcher_free_env())
+    assert two["n_gpus"] == 2 and two["config"]["collective_backend"] == "nccl"
+    assert "ncclAllGather" in two["config"]["collective_path"] and "2 ranks" in two["config"]["collective_path"]
+    one = _bench_line([sys.executable, "bench.py", "--workload", "haystack", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+                       "--no-grid4", "--no-verify", "--max-batch", "64"], _launcher_free_env())
+    assert one["config"]["gathered_keyframes"] == two["config"]["gathered_keyframes"]
+    assert len(two["config"]["host_cpu_sec_per_video_by_rank"]) == 2
+
+
 def test_bench_line_contract():
     """`python bench.py --steps K --warmup W` as the driver runs it at N = 1: exactly one JSON line on stdout with the
     contract's keys, the roofline and cpu_baseline objects, self-consistent figures (value = frames / time, the time shares

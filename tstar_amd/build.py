@@ -27,7 +27,7 @@ ARCH = "gfx950"
 
 # -ffp-contract=off on the searcher file keeps its float64 arithmetic bit-identical
 # to the numpy statement of the reference (no FMA contraction).
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 PER_FILE = {"searcher.hip": ["-ffp-contract=off"]}
 
 

@@ -31,6 +31,7 @@
 #include "kernels.h"
 #include "prof.h"
 #include <type_traits>
+#include <utility>
 
 namespace tstar {
 
@@ -405,12 +406,11 @@ __device__ __forceinline__ void gemm_tile_bf16w(const GemmArgs& g, const int m0,
 //
 // Main loop (different from the tiles above): the WEIGHT planes never touch LDS.  They are packed once per matrix in
 // MFMA-fragment order -- [n-tile of 32 columns][phase q = 3 * (k / 16) + ph][lane][8 bf16], plane 2 - ph, so a wave's
-// B operand of one phase is ONE contiguous 1-KB global_load_dwordx4 -- and stream global -> VGPR through a ring of three
-// fragment sets, two phases (24-48 MFMAs) ahead of their use.  LDS carries only the three activation planes (split while
-// staging, the swizzled 64-B rows of the tiles above): 12-18 MFMAs per loaded KB keep both the LDS (~0.3 busy) and the
-// vector-memory path (~0.5) off the critical path; waves are ready-and-waiting for the matrix pipe 65 % of their cycles.
-// (For the two-term bf16-weight mode the same loop is SLOWER than its LDS tile -- 4 MFMAs per loaded KB put the fragment
-// loads on the 64 B/clk vector-memory path at ~75 % -- so that mode keeps its tile: r04_frag_lab_counters.md.)
+// B operand of one phase is ONE contiguous 1-KB buffer_load_dwordx4 -- and stream global -> VGPR, every fragment a full
+// K = 16 step ahead of its use (gemm_tile_x3 below).  LDS carries only the three activation planes (split while staging, the
+// swizzled 64-B rows of the tiles above).
+// (For the two-term bf16-weight mode a global -> VGPR weight path is SLOWER than its LDS tile -- 4 MFMAs per loaded KB put
+// the fragment loads on the 64 B/clk vector-memory path at ~75 % -- so that mode keeps its tile: r04_frag_lab_counters.md.)
 template <int NA>
 __device__ __forceinline__ void split4_rn(const f32x4 v, u32x2 (&out)[NA]) {
 #pragma unroll
@@ -429,30 +429,74 @@ __device__ __forceinline__ void split4_rn(const f32x4 v, u32x2 (&out)[NA]) {
     }
 }
 
+// one pair of floats -> three packed bf16 pairs (round-to-nearest terms of the running remainder).  Scalar subtractions: packed
+// f32 VALU beside MFMAs costs more than its issue slot (MI355X guide, "price of one filler beside MFMAs")
+__device__ __forceinline__ void split2_rn3(float x0, float x1, unsigned (&o)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        f32x2 x; x[0] = x0; x[1] = x1;
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        o[k] = hb;
+        if (k < 2) {
+            x0 = x0 - __uint_as_float(hb << 16);                      // exact
+            x1 = x1 - __uint_as_float(hb & 0xFFFF0000u);
+        }
+    }
+}
+
+// Round 5: the loop is software-pipelined per WAVE (lab: tools/lab/x3_lab.hip, profiles/r05_x3_lab.log: 181-200 -> 225-242 TFLOP/s
+// algorithmic on the B = 256 shapes, matrix pipe busy 0.60 -> 0.80-0.86; with zero operands, i.e. without the power limit,
+// 2.08 PFLOP/s executed = 0.83 of the dense bf16 peak).  The round-4 loop ran, per K tile, [fragment reads -> wait] 48 MFMAs
+// [reads -> wait] 48 MFMAs [split of the next tile: ~100 VALU] [LDS stores] [barrier], and the compiler had folded its 3-set
+// weight-fragment ring so that most fragment loads were waited for 8-16 MFMAs after their issue: every such section is a hole in
+// the wave's MFMA stream that only the other block's wave on the same SIMD can fill.  Now one wave's stream never waits for
+// something it has just asked for:
+//   * weight fragments: 3 * TN per K = 16 step, each in its OWN 4-register slot, re-loaded for the next step right after its
+//     last MFMA of this step (buffer loads: descriptor + 32-bit lane offset + scalar offset, no 64-bit VALU address math) ->
+//     42-46 MFMAs (1300+ cycles) between a load and its first use;
+//   * MFMA order of a step: per fragment all its products back to back (w0: a2, a1, a0; w1: a1, a0; w2: a0), two column tiles
+//     interleaved so that MFMAs on one accumulator are 2 * TM apart.  Per accumulator and step: a2 w0, a1 w0, a0 w0, a1 w1,
+//     a0 w1, a0 w2 -- the same six exact products as before in another order (rms error vs float64 3.53e-7 at K = 768,
+//     1.45e-6 at K = 3072; round 4's order 3.49e-7 / 1.44e-6; native f32 MFMA tile 4.14e-7 / 1.64e-6);
+//   * activation fragments: a2 / a1 single-buffered and re-read from LDS as soon as their last product of the step has issued
+//     (24 / 8 MFMAs before their next use at TN = 4), a0 double-buffered;
+//   * the split of the NEXT K tile and its LDS stores are cut into pieces that ride between the MFMA groups of the tile's FIRST
+//     step; the ONE barrier per K tile sits between the two steps, where every operand of the second step is already in
+//     registers (RAW: tile kt + 1 is written in step 0 of tile kt and first read in its step 1; WAR: the buffer written in step 0
+//     of tile kt + 1 was last read in step 0 of tile kt, before that tile's barrier -- the wait for those reads precedes it);
+//   * loop body without branches: loads past the end are clamped, the stores of a tile past the end go to the idle buffer.
 template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, const int n0, float* smem_f) {
     constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM;
-    constexpr int NT = 3, D = 3, PPT = 2 * NT;                            // planes per operand, ring depth, phases per K tile
-    constexpr int A_T = BM * 64, BUF = NT * A_T;                          // bytes
+    constexpr int A_T = BM * 64, BUF = 3 * A_T;                           // bytes: one plane, one buffer (three planes)
+    constexpr int NA = BM / 32;                                           // float4 loads per thread per K tile
+    constexpr int PAIR = TN >= 2 ? 2 : 1, GP = TN / PAIR;                 // column tiles interleaved, groups of them
+    static_assert(TN % PAIR == 0, "column tiles go in pairs");
     char* smem = reinterpret_cast<char*>(smem_f);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    constexpr int NA = BM / 32;
     const int c4 = t & 7, r0 = t >> 3;
-    const float* ap[NA];
+    // activation rows: one base per block + a 32-bit byte offset per staged row (clamped to the last row)
+    unsigned aoff[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         int ar = m0 + r0 + 32 * i;
         ar = ar < g.M ? ar : g.M - 1;
-        ap[i] = g.A + (size_t)ar * g.lda + c4 * 4;
+        aoff[i] = (unsigned)(ar - m0) * (unsigned)g.lda * 4u + c4 * 16;
     }
-    const int nph = (g.K / 16) * NT;                                     // KB per n-tile stream
-    const char* wb[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-        wb[j] = static_cast<const char*>(g.Wp) + (size_t)((n0 >> 5) + wn * TN + j) * nph * 1024 + lane * 16;
+    const int nsteps = g.K / 16, nk = g.K / BK;
+    // fragment stream of this wave's column tile j: (j * nsteps + step) * 3072 + ph * 1024 + lane * 16, ph = 2 - kw
+    const char* wrow = static_cast<const char*>(g.Wp) + (size_t)((n0 >> 5) + wn * TN) * nsteps * 3072;
+    const __amdgpu_buffer_rsrc_t ra_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)m0 * g.lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wrow), 0, 0x7fffffff, 0x00020000);
+    const int voff = lane * 16;
+    // LDS (64-B rows, 16-B chunk XOR-swizzled by (row >> 2) & 3): fragment read offsets of step 0 / 1, staging write offset
+    const int rd0 = (wm * TM * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
+    const int rd1 = rd0 ^ 32;
+    const int wr0 = r0 * 64 + (((c4 >> 1) ^ ((r0 >> 2) & 3)) << 4) + (c4 & 1) * 8;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -463,66 +507,157 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[NA];
-    u32x4 ring[D][TN];
+    u32x4 w[3][TN];                                                       // w[kw][j]: plane kw of column tile j, current step
+    bf16x8 a0[2][TM], a1[TM], a2[TM];
+    unsigned sp[2][3];
+
     auto gload_a = [&](int kt) __attribute__((always_inline)) {
+        kt = kt < nk ? kt : nk - 1;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+        for (int i = 0; i < NA; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, (int)aoff[i], kt * (BK * 4), 0));
     };
-    auto lstore = [&](int buf) __attribute__((always_inline)) {
-        char* base = smem + buf * BUF;
+    auto wload = [&](auto KW, auto J, int gs) __attribute__((always_inline)) {
+        constexpr int kw = decltype(KW)::value, j = decltype(J)::value;
+        gs = gs < nsteps ? gs : nsteps - 1;
+        w[kw][j] = __builtin_amdgcn_raw_buffer_load_b128(rw_rsrc, voff + (2 - kw) * 1024, (j * nsteps + gs) * 3072, 0);
+    };
+    auto rd_a = [&](const char* base, int off, int plane, int i) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(base + off + plane * A_T + i * 2048);
+    };
+    // staging piece p of 2 * NA: half p & 1 of float4 p >> 1; the three 8-byte stores follow the second half
+    auto stage_piece = [&](auto P, char* wbase) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value, i = p >> 1, hf = p & 1;
+        split2_rn3(ra[i][2 * hf], ra[i][2 * hf + 1], sp[hf]);
+        if constexpr (hf == 1) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            u32x2 sp[NT];
-            split4_rn<NT>(ra[i], sp);
-            const int off = bfw_off(r0 + 32 * i, c4 >> 1) + (c4 & 1) * 8;
-#pragma unroll
-            for (int k = 0; k < NT; ++k) *reinterpret_cast<u32x2*>(base + k * A_T + off) = sp[k];
+            for (int k = 0; k < 3; ++k) {
+                u32x2 v; v[0] = sp[0][k]; v[1] = sp[1][k];
+                *reinterpret_cast<u32x2*>(wbase + wr0 + k * A_T + i * 2048) = v;
+            }
         }
     };
-    const int nk = g.K / BK;
+    auto mf = [&](const bf16x8& a, const u32x4& b, f32x16& c) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    // one K = 16 step.  S = step inside the tile (selects the a0 set); rbase / roff: where the NEXT step's fragments are read;
+    // wbase: where the next tile's planes go (only S == 0 stages); gnext: fragment-stream step of the reloads; ktload: the tile
+    // whose activations are loaded once the staging registers are free
+    auto step = [&](auto SS, const char* rbase, int roff, char* wbase, int gnext, int ktload) __attribute__((always_inline)) {
+        constexpr int S = decltype(SS)::value;
+        constexpr int NPIECE = NA * 2, NG = 6 * GP, PPG = (NPIECE + 1 + NG - 1) / NG;
+        auto after_group = [&](auto G) __attribute__((always_inline)) {
+            constexpr int gi = decltype(G)::value;
+            if constexpr (S == 0) {
+                [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
+                    ([&] {
+                        constexpr int p = gi * PPG + Q;
+                        if constexpr (p < NPIECE) stage_piece(std::integral_constant<int, p>{}, wbase);
+                        if constexpr (p == NPIECE) gload_a(ktload);
+                    }(), ...);
+                }(std::make_integer_sequence<int, PPG>{});
+            }
+            if constexpr (gi == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[S ^ 1][i] = rd_a(rbase, roff, 0, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // w0 fragments: a2, a1, a0
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = PAIR * JP;
+#pragma unroll
+                for (int jj = 0; jj < PAIR; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a2[i], w[0][j0 + jj], acc[i][j0 + jj]);
+                after_group(std::integral_constant<int, 3 * JP + 0>{});
+#pragma unroll
+                for (int jj = 0; jj < PAIR; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a1[i], w[0][j0 + jj], acc[i][j0 + jj]);
+                after_group(std::integral_constant<int, 3 * JP + 1>{});
+#pragma unroll
+                for (int jj = 0; jj < PAIR; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[0][j0 + jj], acc[i][j0 + jj]);
+                [&]<int... JJ>(std::integer_sequence<int, JJ...>) __attribute__((always_inline)) {
+                    (wload(std::integral_constant<int, 0>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
+                }(std::make_integer_sequence<int, PAIR>{});
+                after_group(std::integral_constant<int, 3 * JP + 2>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+        // a2's last product of the step has issued: the next step's a2
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a2[i] = rd_a(rbase, roff, 2, i);
+        __builtin_amdgcn_sched_barrier(0);
+        // w1 fragments: a1, a0
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = PAIR * JP;
+#pragma unroll
+                for (int jj = 0; jj < PAIR; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a1[i], w[1][j0 + jj], acc[i][j0 + jj]);
+                after_group(std::integral_constant<int, 3 * GP + 2 * JP + 0>{});
+#pragma unroll
+                for (int jj = 0; jj < PAIR; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[1][j0 + jj], acc[i][j0 + jj]);
+                [&]<int... JJ>(std::integer_sequence<int, JJ...>) __attribute__((always_inline)) {
+                    (wload(std::integral_constant<int, 1>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
+                }(std::make_integer_sequence<int, PAIR>{});
+                after_group(std::integral_constant<int, 3 * GP + 2 * JP + 1>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = rd_a(rbase, roff, 1, i);
+        __builtin_amdgcn_sched_barrier(0);
+        // w2 fragments: a0
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = PAIR * JP;
+#pragma unroll
+                for (int jj = 0; jj < PAIR; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[2][j0 + jj], acc[i][j0 + jj]);
+                [&]<int... JJ>(std::integer_sequence<int, JJ...>) __attribute__((always_inline)) {
+                    (wload(std::integral_constant<int, 2>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
+                }(std::make_integer_sequence<int, PAIR>{});
+                after_group(std::integral_constant<int, 5 * GP + JP>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+    };
+
+    // ---- prologue: tile 0 into LDS buffer 0, step 0's weight fragments, tile 1 into the staging registers
     gload_a(0);
-#pragma unroll
-    for (int q = 0; q < D - 1; ++q)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) ring[q][j] = *reinterpret_cast<const u32x4*>(wb[j] + (size_t)(q < nph ? q : nph - 1) * 1024);
-    lstore(0);
+    [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
+        ((wload(std::integral_constant<int, 0>{}, std::integral_constant<int, J>{}, 0),
+          wload(std::integral_constant<int, 1>{}, std::integral_constant<int, J>{}, 0),
+          wload(std::integral_constant<int, 2>{}, std::integral_constant<int, J>{}, 0)), ...);
+    }(std::make_integer_sequence<int, TN>{});
+    [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
+        (stage_piece(std::integral_constant<int, P>{}, smem), ...);
+    }(std::make_integer_sequence<int, NA * 2>{});
+    gload_a(1);
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { a0[0][i] = rd_a(smem, rd0, 0, i); a1[i] = rd_a(smem, rd0, 1, i); a2[i] = rd_a(smem, rd0, 2, i); }
+    // one static priority for the whole loop (over a co-resident block's prologue / epilogue): +1 % in the lab
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) gload_a(kt + 1);
-        const char* base = smem + (kt & 1) * BUF;
-        __builtin_amdgcn_s_setprio(1);
-        bf16x8 fa[NT][TM];
-#pragma unroll
-        for (int P = 0; P < PPT; ++P) {
-            const int s = P / NT, ph = P % NT, kw = NT - 1 - ph;
-            {   // refill the ring two phases ahead (the last phases of the last tile re-read the final KB: never used)
-                int q = kt * PPT + P + D - 1;
-                q = q < nph ? q : nph - 1;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) ring[(P + D - 1) % D][j] = *reinterpret_cast<const u32x4*>(wb[j] + (size_t)q * 1024);
-            }
-            if (ph == 0) {
-#pragma unroll
-                for (int k = 0; k < NT; ++k)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        fa[k][i] = *reinterpret_cast<const bf16x8*>(base + k * A_T + bfw_off(wm * TM * 32 + i * 32 + l31, 2 * s + h));
-            }
-#pragma unroll
-            for (int ka = NT - 1; ka >= 0; --ka) {
-                if (ka + kw > 2) continue;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ka][i], __builtin_bit_cast(bf16x8, ring[P % D][j]), acc[i][j], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (more) lstore((kt + 1) & 1);
-        __syncthreads();
+        char* cur = smem + (kt & 1) * BUF;
+        char* nxt = smem + ((kt + 1) & 1) * BUF;
+        // step 0: the next fragments are this tile's step 1; stages tile kt + 1 into the other buffer, then loads tile kt + 2
+        step(std::integral_constant<int, 0>{}, cur, rd1, nxt, 2 * kt + 1, kt + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // step 1: the next fragments are tile kt + 1, step 0
+        step(std::integral_constant<int, 1>{}, nxt, rd0, nxt, 2 * kt + 2, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
 }
 
