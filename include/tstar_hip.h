@@ -321,6 +321,10 @@ int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int head
 
 /* full attention with f32-split operands on the bf16 matrix pipe (what the bf16-pipe weights modes use) */
 int tstar_attention_split(const float* d_qkv, float* d_out, int B, int T, int heads, void* stream);
+/* full attention with EXACT operands on the bf16 matrix pipe: Q, K, V and the probabilities as three bf16 terms each, six
+ * products per MFMA step, f32 accumulation (what TSTAR_WEIGHTS_F32X3 uses for the vision tower; replaces the fp32
+ * softmax(Q K^T / 8) V of HF modeling_owlvit.py:377-402 behind TStar/interface_heuristic.py:237-239) */
+int tstar_attention_x3(const float* d_qkv, float* d_out, int B, int T, int heads, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream, for bench.py's roofline leg.
  * category 0 = gemm_f32_kernel, 1 = attention_f32_kernel, 2 = conv_valu_kernel (YOLO-World backend).  enable(n > 0) resets the counters and times ONE of every

@@ -410,6 +410,57 @@ def test_attention_split_spiked(lib):
         assert (out.cpu().double() - ref).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("B,T,heads", [(1, 577, 12), (2, 577, 3), (1, 33, 2), (1, 128, 1), (1, 1, 1), (2, 97, 3), (1, 600, 2), (1, 64, 1),
+                                        (1, 65, 1), (3, 193, 2)])
+def test_attention_x3(lib, B, T, heads):
+    """The f32x3 mode's vision attention (round 5): Q (pre-scaled), K, V and the probabilities each as THREE exact bf16 terms,
+    six products per MFMA step on the bf16 matrix pipe, f32 accumulation, software-pipelined over key tiles.  The gate for a
+    bf16-pipe kernel to count as f32: its error against float64 must be no larger than the exact-f32 MFMA kernel's on the
+    same inputs (peaky softmax: scores up to ~ +-25) -- max and rms, both printed."""
+    g = torch.Generator().manual_seed(B * 1000 + T + heads)
+    D = heads * 64
+    qkv = torch.randn(B * T, 3 * D, generator=g)
+    qkv[:, :D] *= 3.0
+    ref = _attn_ref(qkv.double(), B, T, heads)
+    out = torch.full((B * T, D), float("nan"), device="cuda")
+    out32 = torch.empty((B * T, D), device="cuda")
+    dqkv = qkv.cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    _check(lib.tstar_attention_x3(dqkv.data_ptr(), out.data_ptr(), B, T, heads, st))
+    _check(lib.tstar_attention_f32(dqkv.data_ptr(), out32.data_ptr(), B, T, heads, 0, None, st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    e, e32 = (out.cpu().double() - ref), (out32.cpu().double() - ref)
+    err, err32 = e.abs().max().item(), e32.abs().max().item()
+    rms, rms32 = e.pow(2).mean().sqrt().item(), e32.pow(2).mean().sqrt().item()
+    print(f"attention_x3 B={B} T={T} heads={heads}: max err {err:.3e} (f32 kernel {err32:.3e}), rms {rms:.3e} ({rms32:.3e})")
+    assert err < 2e-5
+    assert rms <= rms32 * 1.05 + 1e-9, (rms, rms32)
+    assert err <= 1.5 * err32 + 1e-7, (err, err32)                  # a max over B * T * D elements is a noisy statistic
+
+
+def test_attention_x3_spiked(lib):
+    """Large online-softmax rescales in the pipelined kernel (a dominant key late, an early big one, the straggler key 576
+    dominating): the same bound as the exact-f32 kernel's test."""
+    B, T, heads = 1, 577, 2
+    D = heads * 64
+    for spike_last in (False, True):
+        g = torch.Generator().manual_seed(11)
+        qkv = torch.randn(B * T, 3 * D, generator=g)
+        qkv[500, D:2 * D] *= 40.0
+        qkv[3, D:2 * D] *= 25.0
+        qkv[101, D:2 * D] *= 30.0
+        if spike_last:
+            qkv[576, D:2 * D] *= 60.0
+        ref = _attn_ref(qkv, B, T, heads)
+        out = torch.empty((B * T, D), device="cuda")
+        dqkv = qkv.cuda()
+        _check(lib.tstar_attention_x3(dqkv.data_ptr(), out.data_ptr(), B, T, heads, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        assert (out.cpu() - ref).abs().max().item() < 5e-5
+
+
 def test_attention_causal_padded(lib):
     B, T, heads = 4, 16, 8
     g = torch.Generator().manual_seed(5)

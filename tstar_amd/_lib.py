@@ -76,6 +76,7 @@ SIGNATURES = {
     "tstar_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tstar_draw_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "tstar_attention_split": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tstar_attention_x3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tstar_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tstar_prof_enable": (_i, [_i]),
     "tstar_prof_read": (_i, [_i, _vp, _vp, _vp]),

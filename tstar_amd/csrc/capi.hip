@@ -178,6 +178,12 @@ static GemmArgs mk_gemm(const tstar_owl* h, const float* A, const float* W, floa
     return g;
 }
 
+// TSTAR_X3_ATTN_F32=1: the f32x3 mode with the exact-f32 MFMA attention of rounds 1-4 (same-session A/Bs)
+static bool x3_attention_f32() {
+    static const bool v = getenv("TSTAR_X3_ATTN_F32") != nullptr;
+    return v;
+}
+
 // CLIP pre-LN encoder stack shared by both towers; x [M,D] updated in place
 static int run_encoder(tstar_owl* h, const LayerW* layers, int nlayers, int B, int T, int D, int FF, int heads,
                        int mode, const uint8_t* key_mask, hipStream_t s) {
@@ -186,9 +192,10 @@ static int run_encoder(tstar_owl* h, const LayerW* layers, int nlayers, int B, i
         const LayerW& w = layers[l];
         RC(layernorm_f32(h->x, h->xn, w.ln1_w, w.ln1_b, M, D, s));
         RC(gemm_f32(mk_gemm(h, h->xn, w.qkv_w, h->qkv, w.qkv_b, nullptr, M, 3 * D, D, D, 3 * D, ACT_NONE), s));
-        // full attention in the bf16-WEIGHT modes runs on the bf16 matrix pipe too (operands as two bf16 terms); the f32x3
-        // mode keeps the exact-f32 attention: its claim is an error no larger than the f32 path's
+        // full attention in the bf16-WEIGHT modes runs on the bf16 matrix pipe too (operands as two bf16 terms); in the f32x3
+        // mode with all operand bits (three exact terms, six products: its claim is an error no larger than the f32 path's)
         if (mode == 0 && (h->weights_mode == TSTAR_WEIGHTS_BF16 || h->weights_mode == TSTAR_WEIGHTS_BF16_EXACT)) RC(attention_split(h->qkv, h->att, B, T, heads, s));
+        else if (mode == 0 && h->weights_mode == TSTAR_WEIGHTS_F32X3 && !x3_attention_f32()) RC(attention_x3(h->qkv, h->att, B, T, heads, s));
         else RC(attention_f32(h->qkv, h->att, B, T, heads, mode, key_mask, s));
         RC(gemm_f32(mk_gemm(h, h->att, w.out_w, h->x, w.out_b, h->x, M, D, D, D, D, ACT_NONE), s));
         RC(layernorm_f32(h->x, h->xn, w.ln2_w, w.ln2_b, M, D, s));
@@ -700,6 +707,11 @@ int tstar_attention_f32(const float* d_qkv, float* d_out, int B, int T, int head
 int tstar_draw_boxes(uint8_t* d_images, int B, int H, int W, const float* d_boxes_xyxy, const float* d_scores, void* stream) {
     TSTAR_REQUIRE(d_images && d_boxes_xyxy && d_scores, "tstar_draw_boxes: null argument");
     return draw_boxes(d_images, B, H, W, d_boxes_xyxy, d_scores, V_NP, 0.005f, (hipStream_t)stream);
+}
+
+int tstar_attention_x3(const float* d_qkv, float* d_out, int B, int T, int heads, void* stream) {
+    TSTAR_REQUIRE(d_qkv && d_out, "tstar_attention_x3: null argument");
+    return attention_x3(d_qkv, d_out, B, T, heads, (hipStream_t)stream);
 }
 
 int tstar_attention_split(const float* d_qkv, float* d_out, int B, int T, int heads, void* stream) {

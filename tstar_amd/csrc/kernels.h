@@ -50,4 +50,7 @@ int attention_f32(const float* qkv, float* out, int B, int T, int heads, int mod
 // the same (mode 0 only) on the bf16 matrix pipe: every f32 operand as two bf16 terms, 3 products per MFMA step
 int attention_split(const float* qkv, float* out, int B, int T, int heads, hipStream_t s);
 
+// the same (mode 0 only) with EXACT operands: every f32 operand as three bf16 terms, six products per MFMA step (the f32x3 mode)
+int attention_x3(const float* qkv, float* out, int B, int T, int heads, hipStream_t s);
+
 }  // namespace tstar
