@@ -65,12 +65,15 @@ def parse():
                          "in lock-step an iteration verifies about 228 frames = three chunks of 76 (+ a small remainder)")
     ap.add_argument("--nframes", type=int, default=N_FRAMES)
     ap.add_argument("--search-nframes", type=int, default=8)
-    ap.add_argument("--weights", choices=["f32", "bf16", "bf16_exact", "f32x3"], default="f32",
-                    help="bf16 = BASELINE config 5 (bf16-rounded weights on the bf16 matrix pipe, f32 activations as two bf16 terms: "
+    ap.add_argument("--weights", choices=["f32", "bf16", "bf16_exact", "f32x3"], default="f32x3",
+                    help="f32x3 (default since round 5) = the fp32 checkpoint on the bf16 matrix pipe with every GEMM / attention operand carried as THREE "
+                         "exact bf16 terms (all 24 significand bits), the six partial products with i + j <= 2, f32 accumulation: error vs float64 no "
+                         "larger than the native f32 MFMA kernels' (asserted in tests/test_gpu_kernels.py), detector parity at the same 5e-5 bound; "
+                         "f32 = the native v_mfma_f32_32x32x2_f32 tiles of rounds 1-4 (reported beside the headline as config.f32_native); "
+                         "bf16 = BASELINE config 5 (bf16-rounded weights on the bf16 matrix pipe, f32 activations as two bf16 terms: "
                          "2 MFMA products per algorithmic product); with --nframes 14400 --grid 15 --search-nframes 32 this is "
-                         "configs[4].  bf16_exact = the same weights with the activations split exactly into three terms (3 products). "
-                         "f32x3 = fp32 checkpoint on the bf16 matrix pipe with every operand carried as THREE exact bf16 terms (all 24 bits), "
-                         "six partial products, f32 accumulation (opt-in; GEMM error vs float64 no larger than the f32 MFMA tile's)")
+                         "configs[4].  bf16_exact = the same weights with the activations split exactly into three terms (3 products)."
+                         )
     ap.add_argument("--concurrency", type=int, default=1,
                     help="independent searches in flight per GPU (host threads, one HIP stream + one scorer "
                          "workspace each); 2 fills kernel tails and gives ~+5 %% throughput, but overlapping "
@@ -104,9 +107,9 @@ def parse():
                     help="skip the config.grid4 sub-record (the reference's DEFAULT 4x4 grid, where 'sec/video' is what a user of "
                          "the reference sees: one solo search and 16 videos in lock-step, untimed by the driver)")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip config.other_configs: after the timed region of the DEFAULT line (N = 1, OWL-ViT, f32, configs[1]) bench.py runs "
+                    help="skip config.other_configs: after the timed region of the DEFAULT line (N = 1, OWL-ViT, f32x3, configs[1]) bench.py runs "
                          "itself three more times -- configs[3] (YOLO-World, 48 steps), configs[4] (bf16 weights, 14400 frames, K = 32, grid 15) "
-                         "and the f32x3 mode on configs[1] -- and embeds value / roofline / keyframes_verified of each, so that the driver "
+                         "and configs[1] on the native f32 MFMA tiles (config.f32_native) -- and embeds value / roofline / keyframes_verified of each, so that the driver "
                          "observes them too (about +70 s, none of it inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
@@ -365,13 +368,13 @@ def cpu_baseline_yolo(args, stats):
 
 
 def other_configs():
-    """BASELINE configs[3], configs[4] and the f32x3 mode, each as its own bench.py process AFTER this line's timed region
+    """BASELINE configs[3], configs[4] and configs[1] in the native-f32 mode, each as its own bench.py process AFTER this line's timed region
     (fresh process = its own warm-up, barriers and timed region; nothing shared with the headline).  Summaries only."""
     import subprocess
     runs = {
         "configs[3] yolo": ["--heuristic", "yolo", "--steps", "48"],
         "configs[4] bf16 weights, 14400 frames, K=32, grid 15": ["--weights", "bf16", "--nframes", "14400", "--grid", "15", "--search-nframes", "32", "--steps", "8"],
-        "configs[1] in the f32x3 mode": ["--weights", "f32x3", "--steps", "8"],
+        "configs[1] on the native f32 MFMA tiles (the headline mode of rounds 1-4)": ["--weights", "f32", "--steps", "8"],
     }
     out = {}
     # the children are plain 1-GPU runs of their own: no launcher variables, none of this process's TSTAR_* overrides
@@ -662,12 +665,14 @@ def main():
     # timed process, so the per-launch figure measured with `tools/rocpd_traffic.py` is read from the
     # committed summary (profiles/); None if it has not been collected.
     traffic, traffic_src = None, None
-    for tag in ("r04", "r03", "r02", "r01"):       # the newest collection (tools/collect_profiles.sh) wins
-        tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_gemm_traffic.json")
+    # the newest collection of THIS mode wins (tools/collect_profiles.sh); files without a mode suffix are the native-f32 kernels'
+    sfx = {"f32": "", "f32x3": "_f32x3", "bf16": "_bf16", "bf16_exact": "_bf16_exact"}[args.weights]
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
+        tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_gemm_traffic{sfx}.json")
         if os.path.isfile(tp):
             try:
                 tj = json.load(open(tp))
-                traffic, traffic_src = tj["bytes_per_launch_corrected"], f"profiles/{tag}_pmc_gemm_traffic.json"
+                traffic, traffic_src = tj["bytes_per_launch_corrected"], f"profiles/{tag}_pmc_gemm_traffic{sfx}.json"
                 break
             except Exception:
                 pass
@@ -692,7 +697,7 @@ def main():
         gemm_kernel, peak, exec_mult = "gemm_f32_kernel<WMODE=1> (3 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 3.0
     elif args.weights == "f32x3":
         gemm_kernel, peak, exec_mult = ("gemm_bf16w2_wide_kernel<WMODE=4> / gemm_f32_kernel<WMODE=4> (gemm_tile_x3: 6 x v_mfma_f32_32x32x16_bf16 per K=16, "
-                                        "weight planes global -> VGPR in fragment order)"), BF16_MFMA_PEAK_TFLOPS, 6.0
+                                        "weight planes global -> VGPR in fragment order a full K step ahead, software-pipelined per wave)"), BF16_MFMA_PEAK_TFLOPS, 6.0
     else:
         gemm_kernel, peak, exec_mult = "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, 1.0
     # post-run parity check of the keyframes this run produced (rank 0, step 0): solo re-run + oracle replay, untimed
@@ -703,7 +708,7 @@ def main():
                "haystack32": "configs[2]"}[workload]
     if args.heuristic == "yolo":
         wl_name = "configs[3]" if workload == "single" else wl_name + " with the configs[3] backend"
-    if args.weights != "f32" or args.nframes != N_FRAMES:
+    if args.weights not in ("f32", "f32x3") or args.nframes != N_FRAMES:
         wl_name = "variant of " + wl_name
     det_name = ("YOLO-World-v2-L (seeded synthetic weights, f32 VALU kernels, no MFMA; score > 0.12, top-50)" if args.heuristic == "yolo"
                 else f"OWL-ViT-B/32 {args.weights} weights (seeded synthetic)")
@@ -723,8 +728,10 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": "f32 activations (two round-to-nearest bf16 terms) x bf16 weights, exact products, f32 accumulate",
                       "bf16_exact": "f32 activations x bf16 weights (exact 3-term split on the bf16 MFMA pipe)",
-                      "f32x3": "f32: GEMM operands as 3 exact bf16 terms each (all 24 significand bits), 6 of the 9 partial products (ka + kw <= 2; "
-                               "each exact), f32 accumulate -- GEMM error vs float64 <= the native f32 MFMA tile's (tests); attention / LayerNorm native f32"}[args.weights],
+                      "f32x3": "f32 held exactly as 3 bf16 terms per operand: every GEMM and vision-attention operand (activations, weights, Q, K, V, softmax "
+                               "probabilities) = three round-to-nearest bf16 terms carrying all 24 significand bits; the 6 partial products with i + j <= 2 "
+                               "(each exact) on v_mfma_f32_32x32x16_bf16, f32 accumulate -- error vs float64 <= the native f32 MFMA kernels' (tests); "
+                               "LayerNorm, softmax statistics, epilogues and head tails plain f32"}[args.weights],
             "data": "synthetic",
             "config": {
                 "collective_backend": (backend if world > 1 else None), "collective_path": collective_path,
@@ -764,21 +771,30 @@ def main():
                 "traffic_over_algorithmic": (traffic / (by.value / n_l.value)) if traffic and by.value > 0 and n_l.value else None,
                 "launches_total": n_all.value, "gflop_total": fl_all.value / 1e9,
                 "time_share_of_step": share(fl_all.value, fl.value, ms.value),
-                "attention_f32_kernel": {"achieved": (a_fl.value / (a_ms.value * 1e-3) / 1e12) if a_ms.value > 0 else 0.0,
+                "attention_kernel": {"kernel": "attention_x3_kernel (6 x v_mfma_f32_32x32x16_bf16 per step, exact three-term operands)" if args.weights == "f32x3"
+                                     else ("attention_split_kernel" if args.weights in ("bf16", "bf16_exact") else "attention_f32_kernel"),
+                                     "achieved_algorithmic": (a_fl.value / (a_ms.value * 1e-3) / 1e12) if a_ms.value > 0 else 0.0,
+                                     "executed_over_algorithmic": 6.0 if args.weights == "f32x3" else (3.0 if args.weights in ("bf16", "bf16_exact") else 1.0),
                                          "launches_timed": a_l.value, "launches_total": a_all.value,
                                          "time_share_of_step": share(a_fl_all.value, a_fl.value, a_ms.value)},
             },
         }
         if args.heuristic == "yolo":
-            out["roofline"].pop("attention_f32_kernel", None)
+            out["roofline"].pop("attention_kernel", None)
             out["roofline"]["peak_note"] = "f32 VALU spec peak (v_pk_fma_f32 rate); a tiled f32 VALU GEMM sustains about a third of it on this part (MI355X guide: 52 TFLOP/s)"
         g4rec = None
         if world == 1 and not args.no_grid4 and args.heuristic == "owl" and workload == "single" and g != 4:
             g4rec = grid4_record(heuristics[0], shared_store, args.nframes, args.search_nframes)
             out["config"]["grid4"] = g4rec
-        if (world == 1 and not args.no_other_configs and args.heuristic == "owl" and args.weights == "f32" and workload == "single"
+        if (world == 1 and not args.no_other_configs and args.heuristic == "owl" and args.weights == "f32x3" and workload == "single"
                 and args.nframes == N_FRAMES and g == 16 and args.search_nframes == 8):
             out["config"]["other_configs"] = other_configs()
+            # the native-f32 figure of the same workload beside the headline (what rounds 1-4 reported as `value`)
+            nat = [v for k_, v in out["config"]["other_configs"].items() if "native f32" in k_]
+            if nat and "error" not in nat[0]:
+                out["config"]["f32_native"] = {"value": nat[0]["value"], "unit": nat[0]["unit"], "ms_per_step": nat[0]["ms_per_step"],
+                                               "roofline_frac_of_157.3_TFLOPs": nat[0]["roofline"]["frac"], "keyframes_verified": nat[0]["keyframes_verified"],
+                                               "headline_over_native": out["value"] / nat[0]["value"]}
         if world == 1 and not args.no_cpu_baseline:
             stats_ = {"grid_calls": grid_calls / args.steps, "verify_calls": verify_calls / args.steps, "grid4": g4rec}
             out["cpu_baseline"] = cpu_baseline_yolo(args, stats_) if args.heuristic == "yolo" else cpu_baseline(args, stats_)

@@ -17,7 +17,7 @@ PY="python $ROOT/bench.py"
 : > "$OUT/bench.err"
 $PY --steps 32 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights f32x3 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_f32x3.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights f32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_f32_native.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --weights bf16_exact --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_config5_exact_split.json" 2>> "$OUT/bench.err"
 $PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
@@ -56,13 +56,13 @@ F=$(find /tmp/prof_FETCH_SIZE -name '*.db' | head -1)
 W=$(find /tmp/prof_WRITE_SIZE -name '*.db' | head -1)
 M=$(find /tmp/prof_SQ_VALU_MFMA_BUSY_CYCLES_GRBM_GUI_ACTIVE -name '*.db' | head -1)
 M2=$(find /tmp/prof_SQ_INSTS_VALU_MFMA_MOPS_F32_SQ_BUSY_CYCLES -name '*.db' | head -1)
-python $ROOT/tools/rocpd_traffic.py "$F" "$W" gemm_f32 > "$OUT/${TAG}_pmc_gemm_traffic.json"
+python $ROOT/tools/rocpd_traffic.py "$F" "$W" "gemm_f32|gemm_bf16w2_wide" > "$OUT/${TAG}_pmc_gemm_traffic_f32x3.json"      # the bench default is the f32x3 mode since round 5
 python $ROOT/tools/rocpd_pmc.py "$F" "$W" > "$OUT/${TAG}_pmc_fetch_write_by_kernel.md"
 python $ROOT/tools/rocpd_pmc.py "$M" "$M2" > "$OUT/${TAG}_pmc_mfma_by_kernel.md"
 python $ROOT/tools/rocpd_mfma.py "$M" > "$OUT/${TAG}_pmc_mfma_utilisation.md"
 
 # 4. the bench line (default flags), reading the traffic figure just collected
-cp "$OUT/${TAG}_pmc_gemm_traffic.json" "$ROOT/profiles/${TAG}_pmc_gemm_traffic.json"
+cp "$OUT/${TAG}_pmc_gemm_traffic_f32x3.json" "$ROOT/profiles/${TAG}_pmc_gemm_traffic_f32x3.json"
 $PY > "$OUT/${TAG}_bench.json" 2>> "$OUT/bench.err"
 
 # 5. kernel microbenchmarks

@@ -20,9 +20,10 @@ CLOCK_GHZ = 2.4
 
 def family(name):
     n = re.sub(r"\(.*$", "", name).replace("void ", "").replace("tstar::", "")
-    for f in ("gemm_f32_hybrid_kernel", "gemm_f32_kernel", "attention_f32_kernel"):
+    for f in ("gemm_f32_hybrid_kernel", "gemm_f32_kernel", "gemm_bf16w2_wide_kernel", "attention_f32_kernel", "ax3::attention_x3_kernel",
+              "attention_split_kernel"):
         if n.startswith(f):
-            return "gemm_f32*" if f.startswith("gemm") else f
+            return "gemm_f32* / gemm_bf16w2_wide_kernel (every launch through gemm_f32())" if f.startswith("gemm") else f
     return None
 
 

@@ -9,7 +9,7 @@
                                                                        # roofline.avg_launch_ms| <= 3 % and the number of
                                                                        # dominant-kernel dispatches = stride x launches_timed +- 2 %
 
-Ends with the aggregate over every dispatch of the dominant kernel family (gemm_f32*, or conv_* for the YOLO-World
+Ends with the aggregate over every dispatch of the dominant kernel family (gemm_f32* / gemm_bf16w2_wide_kernel = every launch that goes through gemm_f32(), or conv_* for the YOLO-World
 backend): the figure to compare with bench.py's roofline.avg_launch_ms, which is measured with HIP events inside the
 timed region.
 """
@@ -46,7 +46,7 @@ def main(path, timed=False, bench_json=None, check=False):
         print(f"| `{short(name)}` | {n} | {t/1e6:.3f} | {t/n/1e3:.1f} | {100*t/total:.2f} |")
 
     bj = json.load(open(bench_json)) if bench_json and os.path.isfile(bench_json) else None
-    fam = ("conv_valu_kernel", "conv_sw_kernel", "conv_halo_kernel") if bj and bj.get("roofline", {}).get("bound") == "valu" else ("gemm_f32",)
+    fam = ("conv_valu_kernel", "conv_sw_kernel", "conv_halo_kernel") if bj and bj.get("roofline", {}).get("bound") == "valu" else ("gemm_f32", "gemm_bf16w2_wide_kernel")
     gn = sum(n for name, (n, t) in agg.items() if any(f in name for f in fam))
     gt = sum(t for name, (n, t) in agg.items() if any(f in name for f in fam))
     ok = True
