@@ -31,6 +31,8 @@ from __future__ import annotations
 
 import math
 
+import functools
+
 import numpy as np
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
@@ -118,8 +120,20 @@ def patchify(pixel_values: np.ndarray) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- bilinear
+@functools.lru_cache(maxsize=64)
+def _cv_linear_table_cached(src: int, dst: int):
+    t = cv_linear_table.__wrapped__(src, dst)
+    t.setflags(write=False)
+    return t
+
+
 def cv_linear_table(src: int, dst: int):
-    """Per output index: (s0, s1, w0, w1); float arithmetic as in cv::resize's coefficient loop."""
+    """Per output index: (s0, s1, w0, w1); float arithmetic as in cv::resize's coefficient loop.  (Cached per (src, dst): the
+    loop below is pure Python; callers get a read-only array.)"""
+    return _cv_linear_table_cached(int(src), int(dst))
+
+
+def _cv_linear_table_uncached(src: int, dst: int):
     scale = float(src) / float(dst)
     tab = np.zeros((dst, 4), dtype=np.int64)
     for d in range(dst):
@@ -137,13 +151,18 @@ def cv_linear_table(src: int, dst: int):
     return tab
 
 
+cv_linear_table.__wrapped__ = _cv_linear_table_uncached
+
+
 def cv_bilinear_resize(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
     """uint8 [H,W,C] -> uint8 [out_h,out_w,C]."""
     assert img.dtype == np.uint8 and img.ndim == 3
     H, W, _ = img.shape
     tx = cv_linear_table(W, out_w)
     ty = cv_linear_table(H, out_h)
-    s = img.astype(np.int64)
+    s = img.astype(np.int32)       # every intermediate stays below 2^27: int32 gives the same integers as int64, faster
+    tx = tx.astype(np.int32)
+    ty = ty.astype(np.int32)
     # horizontal pass on every needed source row: int = S[s0]*w0 + S[s1]*w1
     hp = s[:, tx[:, 0], :] * tx[:, 2][None, :, None] + s[:, tx[:, 1], :] * tx[:, 3][None, :, None]
     r0 = hp[ty[:, 0]] >> 4

@@ -488,20 +488,22 @@ def test_g1_reference_trajectories_on_device(golden_dir, case):
     assert s.remaining_targets + ["<end>"] == g["remaining"].tolist()
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32x3"])
 @pytest.mark.parametrize("name", ["g9_end_to_end.npz", "g9b_end_to_end_3600.npz"])
-def test_g9_end_to_end_vs_reference(golden_dir, name):
+def test_g9_end_to_end_vs_reference(golden_dir, name, mode):
     """The full HIP pipeline against the reference's own end-to-end runs (reference searcher + reference
     OWLInterface on HF transformers, CPU; G9: 160 frames, 4 iterations, 48 detector calls; G9b, round 4: the 3600-frame
     video at the reference-default 4x4 grid, K = 8, budget cut to 3 iterations, 29 calls): first-iteration per-frame
     confidences within 1e-3; while the trajectories coincide, every later confidence too; identical keyframes when they
-    coincide to the end (closed-loop equality is chaotic -- SURVEY.md 7 -- so it is reported, the per-score bound is gated)."""
+    coincide to the end (closed-loop equality is chaotic -- SURVEY.md 7 -- so it is reported, the per-score bound is gated).
+    Both detector arithmetic modes: the native f32 MFMA tiles and the bench's headline f32x3 mode (round 5)."""
     from tstar_amd.interface_heuristic import OWLInterface
     from tstar_amd.interface_searcher import TStarSearcher
     from tstar_amd.video import synthetic_video
     g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
     N, grid, K, np_seed, vseed, ncalls = [int(v) for v in g["meta"]]
     budget = float(g["budget"]) if "budget" in g.files else 0.4
-    h = OWLInterface(synthetic_seed=0, max_batch=16)
+    h = OWLInterface(synthetic_seed=0, max_batch=16, weights_dtype=mode)
     rec = _Recorder(h)
     s = TStarSearcher(synthetic_video(N, seed=vseed), h, ["couch"], ["tv", "chair"], search_nframes=K,
                       image_grid_shape=(grid, grid), search_budget=budget, confidence_threshold=0.6,
@@ -524,7 +526,7 @@ def test_g9_end_to_end_vs_reference(golden_dir, name):
     if same == len(ref_secs) and len(log) == len(ref_secs):
         assert [float(t) for t in ts] == g["time_stamps"].tolist()
         assert s.detector_calls == ncalls
-    print(f"{name}: {same}/{len(ref_secs)} iterations on the reference trajectory; keyframes "
+    print(f"{name} [{mode}]: {same}/{len(ref_secs)} iterations on the reference trajectory; keyframes "
           f"{[float(t) for t in ts]} vs reference {g['time_stamps'].tolist()}")
 
 

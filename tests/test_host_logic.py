@@ -582,23 +582,31 @@ def test_native_curfit_bit_identical_to_scipy(golden_dir):
 
 
 def test_spline_worker_count_follows_the_affinity_mask(monkeypatch):
-    """Round-3 review item 7: the FITPACK workers of a rank are sized from the hardware threads the process may run on, and
-    the node total stays within half of them whether the mask is the whole host (divided by LOCAL_WORLD_SIZE), a container's
-    cpuset shared by the ranks (divided too) or a per-rank cpuset (taken as the rank's share)."""
+    """The FITPACK workers of a rank are sized from the hardware threads the process may run on (its affinity mask, capped by the
+    cgroup's CPU quota), ALWAYS divided by LOCAL_WORLD_SIZE (round-4 advisor: a narrow cpuset shared by all ranks cannot be told
+    from a per-rank one from inside a rank; the conservative split never oversubscribes), unless the launcher declares a per-rank
+    mask; the node total stays within half the usable threads."""
     from tstar_amd import spline_pool as SP
 
-    def workers(mask, cpus, ranks):
+    def workers(mask, cpus, ranks, quota=None, per_rank=False):
         monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(mask)))
         monkeypatch.setattr(os, "cpu_count", lambda: cpus)
+        monkeypatch.setattr(SP, "cgroup_cpu_quota", lambda: quota)
         monkeypatch.setenv("LOCAL_WORLD_SIZE", str(ranks))
         monkeypatch.delenv("TSTAR_SPLINE_WORKERS", raising=False)
+        if per_rank:
+            monkeypatch.setenv("TSTAR_SPLINE_MASK_PER_RANK", "1")
+        else:
+            monkeypatch.delenv("TSTAR_SPLINE_MASK_PER_RANK", raising=False)
         return SP.default_workers()
 
     assert workers(256, 256, 1) == 16 and workers(256, 256, 8) == 16        # whole host: 256 / 8 / 2 = 16
-    assert workers(32, 256, 8) == 16                                          # per-rank cpuset of 32 threads: the rank's own share
+    assert workers(32, 256, 8) == 2                                           # a 32-thread cpuset, shared for all we know: 32 / 8 / 2
+    assert workers(32, 256, 8, per_rank=True) == 16                           # ... unless the launcher says it is this rank's own
     assert workers(64, 256, 8) == 4                                           # a 64-thread container shared by 8 ranks: 64 / 8 / 2
+    assert workers(256, 256, 8, quota=32.0) == 2                              # a CPU quota without a cpuset counts too
     assert workers(8, 8, 2) == 2 and workers(2, 2, 8) == 1
-    for mask, cpus, ranks in ((256, 256, 8), (64, 256, 8), (8, 8, 2), (128, 128, 4)):
+    for mask, cpus, ranks in ((256, 256, 8), (64, 256, 8), (32, 256, 8), (8, 8, 2), (128, 128, 4)):
         assert workers(mask, cpus, ranks) * ranks <= max(ranks, mask // 2)
     monkeypatch.setenv("TSTAR_SPLINE_WORKERS", "3")
     assert SP.default_workers() == 3

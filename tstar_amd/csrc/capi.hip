@@ -661,7 +661,7 @@ int tstar_gemm_bf16w2(const float* d_A, const float* d_W, float* d_C, const floa
 int tstar_gemm_f32x3(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual, int M,
                      int N, int K, int act, int tile_cfg, void* stream) {
     TSTAR_REQUIRE(d_A && d_W && d_C, "tstar_gemm_f32x3: null argument");
-    TSTAR_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "tstar_gemm_f32x3: N must be a multiple of 32, K of 16");
+    TSTAR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 32 == 0, "tstar_gemm_f32x3: N must be a multiple of 128, K of 32 (include/tstar_hip.h)");
     hipStream_t s = (hipStream_t)stream;
     void* wp = nullptr;
     TSTAR_HIP_CHECK(hipMalloc(&wp, (size_t)N * K * 6));
@@ -687,6 +687,7 @@ int tstar_pack_f32x3(const float* d_W, void* d_Wp, int N, int K, void* stream) {
 int tstar_gemm_f32x3_pre(const float* d_A, const void* d_Wp, float* d_C, const float* d_bias, const float* d_residual, int M, int N,
                          int K, int act, int tile_cfg, void* stream) {
     TSTAR_REQUIRE(d_A && d_Wp && d_C, "tstar_gemm_f32x3_pre: null argument");
+    TSTAR_REQUIRE(M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 32 == 0, "tstar_gemm_f32x3_pre: N must be a multiple of 128, K of 32 (include/tstar_hip.h)");
     GemmArgs g = mk_gemm(nullptr, d_A, reinterpret_cast<const float*>(d_Wp), d_C, d_bias, d_residual, M, N, K, K, N, act);
     g.Wp = d_Wp;
     g.tile_cfg = tile_cfg;

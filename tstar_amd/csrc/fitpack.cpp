@@ -1,3 +1,8 @@
+// Attribution: the algorithm restated here is FITPACK (P. Dierckx, K.U. Leuven; distributed through netlib -- netlib.org/dierckx --
+// and wrapped by scipy.interpolate, BSD-licensed there).  Routine and variable names (fpcurf, fpknot, fpdisc, fpgivs, fprota, fprati,
+// fpbspl, fpback; store, dd, stor1 ...) follow the library so that the two can be read side by side; the code itself was
+// written for this tree from the published description and from scipy's observable behaviour.
+//
 // Host-side smoothing-spline fit of the T* sampling distribution: a C++ restatement of P. Dierckx's FITPACK `curfit`
 // (fpcurf / fpknot / fpdisc / fpgivs / fprota / fprati / fpbspl / fpback) for the one call the reference makes --
 //     scipy.interpolate.UnivariateSpline(visited_indices, observed_scores, s=0.5)
@@ -23,7 +28,12 @@
 // the library's two branches compute).  The widest form the CPU supports is picked at run time; all forms give the same bits.
 //
 // Not on the GPU: the fit is a few hundred KB of sequential, latency-bound float64 work per search iteration.
+#if defined(__x86_64__)
 #include <immintrin.h>
+#define TSTAR_FITPACK_SIMD 1
+#else
+#define TSTAR_FITPACK_SIMD 0          // other hosts: the sequential form only (same bits)
+#endif
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -296,6 +306,7 @@ inline void rotate_rows_skewed(RowState<W>& st, double* g, int gs, double* c, in
     STOREU(g1 + base, G1); STOREU(g2 + base, G2); STOREU(g3 + base, G3); STOREU(g4 + base, G4); STOREU(g5 + base, G5); STOREU(c + base, CC); \
     STOREU(st.h1, H1); STOREU(st.h2, H2); STOREU(st.h3, H3); STOREU(st.h4, H4); STOREU(st.h5, H5); STOREU(st.yi, YI);
 
+#if TSTAR_FITPACK_SIMD
 __attribute__((target("avx512f,avx512dq"))) inline void steady8(RowState<8>& st, double* g, int gs, double* c, int it0, int T0, int T1) {
     constexpr int W = 8;
     double* g1 = g + PAD; double* g2 = g + gs + PAD; double* g3 = g + 2 * gs + PAD; double* g4 = g + 3 * gs + PAD; double* g5 = g + 4 * gs + PAD;
@@ -317,6 +328,8 @@ __attribute__((target("avx2"))) inline void steady4(RowState<4>& st, double* g, 
                       _mm256_sqrt_pd, ABS256, SEL256, LANE256, SHIFT256, _mm256_setzero_pd)
 }
 
+#endif
+
 template <int W>
 inline void rotate_batch(const double* b, double pinv, double* g, int gs, double* c, int it0, int nk1, int n8) {
     RowState<W> st;
@@ -330,8 +343,10 @@ inline void rotate_batch(const double* b, double pinv, double* g, int gs, double
     const int s0 = 2 * (W - 1), s1 = n8 - it0;           // steady state: every lane started, top lane's column it0 + T <= n8
     if (s1 >= s0) {
         rotate_rows_skewed<W>(st, g, gs, c, it0, nk1, n8, 0, s0 - 1);
+#if TSTAR_FITPACK_SIMD
         if constexpr (W == 8) steady8(st, g, gs, c, it0, s0, s1);
         else steady4(st, g, gs, c, it0, s0, s1);
+#endif
         rotate_rows_skewed<W>(st, g, gs, c, it0, nk1, n8, s1 + 1, t_end);
     } else {
         rotate_rows_skewed<W>(st, g, gs, c, it0, nk1, n8, 0, t_end);
@@ -579,12 +594,14 @@ int curfit_impl(const double* x0, const double* y0, int m, double s, double* t_o
     return ier;
 }
 
+#if TSTAR_FITPACK_SIMD
 __attribute__((target("avx512f,avx512dq"))) int curfit_avx512(const double* x, const double* y, int m, double s, double* t, double* c, int* n, double* fp, int* it) {
     return curfit_impl<8>(x, y, m, s, t, c, n, fp, it);
 }
 __attribute__((target("avx2"))) int curfit_avx2(const double* x, const double* y, int m, double s, double* t, double* c, int* n, double* fp, int* it) {
     return curfit_impl<4>(x, y, m, s, t, c, n, fp, it);
 }
+#endif
 int curfit_scalar(const double* x, const double* y, int m, double s, double* t, double* c, int* n, double* fp, int* it) {
     return curfit_impl<1>(x, y, m, s, t, c, n, fp, it);
 }
@@ -599,16 +616,23 @@ extern "C" {
 int tstar_curfit(const double* x, const double* y, int m, double s, int lanes, double* t, double* c, int* n, double* fp, int* p_iterations) {
     if (!x || !y || !t || !c || !n || !fp || m < 4 || !(s >= 0.0)) return 10;
     for (int i = 1; i < m; ++i) if (!(x[i] > x[i - 1])) return 10;
+#if TSTAR_FITPACK_SIMD
     __builtin_cpu_init();
     if (lanes == 0) lanes = (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq")) ? 8 : (__builtin_cpu_supports("avx2") ? 4 : 1);
     if (lanes == 8 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq")) return curfit_avx512(x, y, m, s, t, c, n, fp, p_iterations);
     if (lanes >= 4 && __builtin_cpu_supports("avx2")) return curfit_avx2(x, y, m, s, t, c, n, fp, p_iterations);
+#endif
+    (void)lanes;
     return curfit_scalar(x, y, m, s, t, c, n, fp, p_iterations);
 }
 
 int tstar_curfit_lanes(void) {
+#if TSTAR_FITPACK_SIMD
     __builtin_cpu_init();
     return (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq")) ? 8 : (__builtin_cpu_supports("avx2") ? 4 : 1);
+#else
+    return 1;
+#endif
 }
 
 }  // extern "C"

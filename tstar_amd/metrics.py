@@ -61,32 +61,32 @@ def calculate_ssim_scores(list_gt_images: List[List[np.ndarray]], list_pred_imag
     return out
 
 
-def calculate_prf(list_gt: List[np.ndarray], list_pred: List[np.ndarray], threshold: int = 5) -> Tuple[float, float, float]:
-    """(:186-214) average temporal precision / recall / F1 with a +-threshold match."""
-    ps, rs, fs = [], [], []
+def _temporal_pairs(list_gt, list_pred):
+    """Per video with both lists non-empty: (distance of every ground-truth second to its nearest prediction, distance of every
+    predicted second to its nearest ground-truth second) from ONE |gt - pred| matrix."""
     for gt, pred in zip(list_gt, list_pred):
         gt, pred = np.asarray(gt), np.asarray(pred)
-        if gt.size == 0 or pred.size == 0:
-            continue
-        d_gt = np.min(np.abs(gt[:, np.newaxis] - pred), axis=1)
-        d_pr = np.min(np.abs(pred[:, np.newaxis] - gt), axis=1)
-        precision = np.sum(d_pr <= threshold) / len(pred)
-        recall = np.sum(d_gt <= threshold) / len(gt)
-        f1 = 2 * (precision * recall) / (precision + recall) if (precision + recall) > 0 else 0.0
-        ps.append(precision)
-        rs.append(recall)
-        fs.append(f1)
-    return (np.mean(ps) if ps else 0.0, np.mean(rs) if rs else 0.0, np.mean(fs) if fs else 0.0)
+        if gt.size and pred.size:
+            dist = np.abs(np.subtract.outer(gt, pred))           # [len(gt), len(pred)]
+            yield dist.min(axis=1), dist.min(axis=0)
+
+
+def calculate_prf(list_gt: List[np.ndarray], list_pred: List[np.ndarray], threshold: int = 5) -> Tuple[float, float, float]:
+    """Temporal precision / recall / F1 averaged over the videos, a second counting as matched when its nearest counterpart is
+    within +-threshold (the evaluator's definition: LVHaystackBench/val_tstar_results.py:186-214)."""
+    rows = []
+    for gt_to_pred, pred_to_gt in _temporal_pairs(list_gt, list_pred):
+        precision = np.count_nonzero(pred_to_gt <= threshold) / pred_to_gt.size
+        recall = np.count_nonzero(gt_to_pred <= threshold) / gt_to_pred.size
+        both = precision + recall
+        rows.append((precision, recall, 2 * (precision * recall) / both if both > 0 else 0.0))
+    if not rows:
+        return 0.0, 0.0, 0.0
+    p, r, f = (np.mean(col) for col in zip(*rows))
+    return p, r, f
 
 
 def calculate_annd(list_gt: List[np.ndarray], list_pred: List[np.ndarray]) -> List[Tuple[float, float]]:
-    """(:241-256) average nearest-neighbour distance per video: (prediction -> gt, gt -> prediction)."""
-    out = []
-    for gt, pred in zip(list_gt, list_pred):
-        gt, pred = np.asarray(gt), np.asarray(pred)
-        if gt.size == 0 or pred.size == 0:
-            continue
-        d_gt = np.min(np.abs(gt[:, np.newaxis] - pred), axis=1)
-        d_pr = np.min(np.abs(pred[:, np.newaxis] - gt), axis=1)
-        out.append((np.mean(d_pr), np.mean(d_gt)))
-    return out
+    """Average nearest-neighbour distance per video, (prediction -> ground truth, ground truth -> prediction)
+    (val_tstar_results.py:241-256)."""
+    return [(np.mean(pred_to_gt), np.mean(gt_to_pred)) for gt_to_pred, pred_to_gt in _temporal_pairs(list_gt, list_pred)]

@@ -38,18 +38,44 @@ def host_threads() -> int:
         return max(1, os.cpu_count() or 1)
 
 
+def cgroup_cpu_quota() -> Optional[float]:
+    """CPUs' worth of time the cgroup allows this process (cpu.max of cgroup v2, cfs quota of v1), or None when unlimited / unknown:
+    a quota without a cpuset does not show in the affinity mask."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        if q > 0 and per > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def default_workers() -> int:
-    """TSTAR_SPLINE_WORKERS, else up to 16 workers out of half this rank's share of the host threads it may use.  The affinity
-    mask is either the rank's own cpuset (a launcher that pins ranks: the mask is about machine / ranks wide and IS the share) or
-    a set all local ranks run on (the whole host, or a container's cpuset: then it is divided by LOCAL_WORLD_SIZE) -- told apart by
-    its width, so the node total stays <= half the usable threads either way."""
+    """TSTAR_SPLINE_WORKERS, else up to 16 workers out of half this rank's share of the host threads it may use.  The share is the
+    CONSERVATIVE split: (affinity mask, capped by the cgroup's CPU quota) // LOCAL_WORLD_SIZE -- whether the mask is the whole host, a
+    container cpuset all local ranks share, or a per-rank cpuset cannot be told from inside one rank (a narrow shared cpuset looks
+    like a per-rank one), and taking a shared mask for a private one oversubscribes the host 8-fold, while the opposite mistake
+    only leaves workers unused.  A launcher that pins each rank to its own cpuset says so with TSTAR_SPLINE_MASK_PER_RANK=1 (the
+    mask is then the share), or sets TSTAR_SPLINE_WORKERS outright."""
     env = os.environ.get("TSTAR_SPLINE_WORKERS")
     if env is not None:
         return max(0, int(env))
     ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     usable = host_threads()
-    per_rank_mask = ranks > 1 and usable * ranks <= 1.5 * (os.cpu_count() or usable)
-    share = usable if per_rank_mask else usable // ranks
+    quota = cgroup_cpu_quota()
+    if quota is not None:
+        usable = max(1, min(usable, int(quota)))
+    share = usable if os.environ.get("TSTAR_SPLINE_MASK_PER_RANK") == "1" else usable // ranks
     return max(1, min(16, share // 2))
 
 
@@ -99,11 +125,20 @@ class SplinePool:
         self._procs = []
 
     @staticmethod
+    def _checked(problems):
+        """Every (x, y) as contiguous float64 1-D arrays of equal length -- raised BEFORE a byte goes to a worker: a caller's
+        mistake must not cost the pool (a half-served pool cannot be resynchronised and is closed)."""
+        out = []
+        for x, y in problems:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            if x.shape != y.shape or x.ndim != 1:
+                raise ValueError("spline fit needs two 1-D arrays of equal length")
+            out.append((x, y))
+        return out
+
+    @staticmethod
     def _send(p: subprocess.Popen, x: np.ndarray, y: np.ndarray, s: float, n_frames: int = 0):
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        y = np.ascontiguousarray(y, dtype=np.float64)
-        if x.shape != y.shape or x.ndim != 1:
-            raise ValueError("spline fit needs two 1-D arrays of equal length")
         p.stdin.write(struct.pack("<qdq", len(x), float(s), int(n_frames)) + x.tobytes() + y.tobytes())
         p.stdin.flush()
 
@@ -134,6 +169,7 @@ class SplinePool:
             raise ValueError("fit_many: one n_frames per problem")
         if not self._procs:
             raise SplinePoolError("spline pool is closed")
+        problems = self._checked(problems)
         out: List[Optional[Tuple[np.ndarray, np.ndarray, int]]] = [None] * len(problems)
         with self._lock:
             if not self._procs:
@@ -156,6 +192,7 @@ class SplinePool:
         """Hand at most len(self) problems to the workers and return at once (the pool stays locked until ``end``)."""
         if len(problems) > len(self._procs) or len(n_frames) != len(problems):
             raise ValueError("SplinePool.begin: at most one problem per worker, one n_frames per problem")
+        problems = self._checked(problems)
         self._lock.acquire()
         try:
             if not self._procs:
@@ -222,8 +259,8 @@ def fit_many(problems: Sequence[Tuple[np.ndarray, np.ndarray]], s: float = 0.5):
     out = _pooled(problems, s, 0)
     if out is not None:
         return out
-    from scipy.interpolate import UnivariateSpline
-    return [UnivariateSpline(x, y, s=s)._eval_args for x, y in problems]
+    from .spline_worker import fit_tck         # the workers' own fit (native restatement when built, else scipy): same bits, same speed
+    return [fit_tck(np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64), s) for x, y in problems]
 
 
 def distribution_many(problems: Sequence[Tuple[np.ndarray, np.ndarray]], n_frames: Sequence[int], s: float = 0.5):

@@ -66,6 +66,16 @@ def curfit(x, y, s: float = 0.5, lanes: int = 0):
     return t[:n.value], c[:n.value], 3, fp.value, ier
 
 
+def fit_tck(x, y, s: float = 0.5):
+    """``UnivariateSpline(x, y, s=s)._eval_args`` = (t, c, k): through the native restatement when it applies (bit-identical), else
+    scipy's own call -- what a worker answers to a plain fit request, and what the in-process fallback of spline_pool.fit_many runs."""
+    fit = curfit(x, y, s)
+    if fit is not None:
+        return fit[:3]
+    from scipy.interpolate import UnivariateSpline
+    return UnivariateSpline(x, y, s=s)._eval_args
+
+
 def spline_distribution(visited_indices, observed_scores, video_length: int, s: float = 0.5):
     """spline_keyframe_distribution after the visited frames have been extracted
     (/root/reference/TStar/interface_searcher.py:262-274): uniform when nothing was visited; else the smoothing
@@ -100,7 +110,6 @@ def _read(f, n):
 
 def main():
     import numpy as np
-    from scipy.interpolate import UnivariateSpline
     inp, out = sys.stdin.buffer, sys.stdout.buffer
     while True:
         hdr = inp.read(24)
@@ -117,8 +126,7 @@ def main():
                 P = np.ascontiguousarray(spline_distribution(x, y, int(N), s), dtype=np.float64)
                 out.write(struct.pack("<qqq", 0, 8 * len(P), -1) + P.tobytes())
             else:
-                fit = curfit(x, y, s)
-                t, c, k = fit[:3] if fit is not None else UnivariateSpline(x, y, s=s)._eval_args
+                t, c, k = fit_tck(x, y, s)
                 t = np.ascontiguousarray(t, dtype=np.float64)
                 cc = np.zeros(len(t), dtype=np.float64)
                 cc[:len(c)] = c
