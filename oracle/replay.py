@@ -26,14 +26,19 @@ class Recorder:
 
         def rec(d_images, rows, cols, image_sets=None):
             r = self._orig(d_images, rows, cols, image_sets=image_sets)
-            self.calls.append(dict(rows=rows, cols=cols, images=d_images.cpu().numpy() if keep_images else None,
+            self.calls.append(dict(_res=r, rows=rows, cols=cols, images=d_images.cpu().numpy() if keep_images else None,
                                    conf=r.cell_conf.cpu().numpy(), mask=r.cell_mask.cpu().numpy().astype(np.uint32),
                                    scores=r.scores.cpu().numpy(), boxes=r.boxes.cpu().numpy(), labels=r.labels.cpu().numpy()))
             return r
         h.score_batch = rec
+        # a grid forward the searcher queued speculatively and then discarded (tstar_amd.lockstep._Group.speculate: the search ended
+        # with the verification batch before it) is not something the searcher CONSUMED: drop its record
+        h._speculation_dropped = lambda res: self.calls.__setitem__(slice(None), [c for c in self.calls if c["_res"] is not res])
 
     def restore(self):
         self.h.score_batch = self._orig
+        if hasattr(self.h, "_speculation_dropped"):
+            del self.h._speculation_dropped
 
 
 def replay_through_oracle(calls, texts, targets, cues, N, g, K, budget, thr, seed):

@@ -192,13 +192,16 @@ class _Recorder:
         self.calls = []
         self._orig = h.score_batch
 
-        def rec(d_images, rows, cols):
-            r = self._orig(d_images, rows, cols)
-            self.calls.append(dict(rows=rows, cols=cols, images=d_images.cpu().numpy(),
+        def rec(d_images, rows, cols, image_sets=None):
+            r = self._orig(d_images, rows, cols, image_sets=image_sets)
+            self.calls.append(dict(_res=r, rows=rows, cols=cols, images=d_images.cpu().numpy(),
                                    conf=r.cell_conf.cpu().numpy(), mask=r.cell_mask.cpu().numpy().astype(np.uint32),
                                    scores=r.scores.cpu().numpy(), boxes=r.boxes.cpu().numpy(), labels=r.labels.cpu().numpy()))
             return r
         h.score_batch = rec
+        # a speculatively queued grid forward that the searcher discarded (the search ended with the verification batch before it:
+        # tstar_amd.lockstep._Group.speculate) was never CONSUMED -- its record goes too
+        h._speculation_dropped = lambda res: self.calls.__setitem__(slice(None), [c for c in self.calls if c["_res"] is not res])
 
 
 def test_l2_teacher_forced_end_to_end():

@@ -20,6 +20,8 @@ iteration, budget overshoot.  ``search_with_visualization`` is ``search`` (:493-
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Optional, Tuple
 
@@ -453,6 +455,10 @@ class TStarSearcher:
         return secs, _ResizedFrames(self, secs, CELL_W * 4, CELL_H * 4)
 
     def _sample_secs(self, num_samples: int) -> List[int]:
+        pre = getattr(self, "_prefetched_secs", None)
+        if pre is not None:                     # drawn ahead by lockstep._Group.speculate() from the same generator state
+            self._prefetched_secs = None
+            return pre
         if num_samples > self.total_frame_num:
             num_samples = self.total_frame_num
         if not self.Score_history:
@@ -583,8 +589,16 @@ class TStarSearcher:
                         break
 
     def search(self):
-        """(:444-491) returns (keyframes uint8 [K,H,W,3], time_stamps list[float])."""
+        """(:444-491) returns (keyframes uint8 [K,H,W,3], time_stamps list[float]).
+
+        On the fast path (a tstar_amd detector interface) the loop below is executed by ``lockstep.search_solo``: the same
+        statements in the same order, with the searcher-state kernels on a side stream and the next iteration's grid forward
+        queued speculatively behind each verification batch (identical results: tests/test_gpu_searcher.py).
+        ``TSTAR_SOLO_SEQUENTIAL=1`` runs the plain loop (same-session A/Bs)."""
         import torch
+        if self._fast and os.environ.get("TSTAR_SOLO_SEQUENTIAL") is None:
+            from .lockstep import search_solo
+            return search_solo(self)
         while self.remaining_targets and self.search_budget > 0:
             rows, cols = self.image_grid_shape
             n = rows * cols

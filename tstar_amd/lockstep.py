@@ -20,6 +20,7 @@ everything queued behind it by the other group.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -30,6 +31,7 @@ from .interface_searcher import TStarSearcher
 MAX_GROUP = 63          # TSTAR_OWL_MAX_SETS - 1 query-set slots (include/tstar_hip.h); slot 0 stays the heuristic's own
 
 _SIDE = {}              # device index -> the side stream of the searcher-state kernels
+_SPECULATE = os.environ.get("TSTAR_NO_SPECULATION") is None      # TSTAR_NO_SPECULATION=1: same-session A/Bs of speculate()
 
 
 def _side_stream(torch):
@@ -55,11 +57,16 @@ class _Group:
         self.side = _side_stream(torch)
         self.pending = None            # the verification batch in flight (end() consumes it)
         self.act = []
+        self.spec = None               # the NEXT iteration's samples / grid forward, queued speculatively (see speculate())
+        self.solo = False              # one searcher driven through its own slot 0 and its public sample_frames hook
 
     def install(self):
         h = self.h
         self.side.wait_stream(self.main)          # state written on the caller's stream before the search (once: a wait per
                                                   # iteration would queue the samples behind the other group's batch)
+        if self.solo:                             # the searcher's own question sits in slot 0 since its constructor
+            self.act = self._active()
+            return
         if hasattr(h, "install_queries_many"):                   # one text-tower forward for the whole group's questions
             texts = h.install_queries_many([(s._slot, s.target_objects, s.cue_objects, s.object2weight) for s in self.ss])
             for s, t in zip(self.ss, texts):
@@ -72,20 +79,78 @@ class _Group:
     def _active(self):
         return [s for s in self.ss if s.remaining_targets and s.search_budget > 0]
 
+    def _sets(self, items):
+        return None if self.solo else [s._slot for s in items]
+
+    def _draw(self, s):
+        """The iteration's samples of one searcher.  A searcher running alone goes through its public ``sample_frames`` (the
+        reference's call: wrappers / subclasses see exactly one call per executed iteration, at the reference's place)."""
+        return [int(v) for v in s.sample_frames(self.n)[0]] if self.solo else s._sample_secs(self.n)
+
     def begin(self):
-        """Samples of the iteration (state kernels, side stream), grid images and the grid forward (detector stream)."""
+        """Samples of the iteration (state kernels, side stream), grid images and the grid forward (detector stream) -- or, when
+        ``speculate()`` queued exactly this iteration behind the previous verification batch, nothing but taking it over."""
         torch = self.torch
+        if self.spec is not None:
+            items, secs_l, grids, res, ev, _ = self.spec
+            self.spec = None
+            if items == self.act:                 # every speculated item is still searching (and no other is): the work is already queued
+                if self.solo:                     # the hook sees the draw now, at the reference's place
+                    for s, secs in zip(items, secs_l):
+                        s._prefetched_secs = list(secs)
+                        got = [int(v) for v in s.sample_frames(self.n)[0]]
+                        assert got == secs, "a sample_frames override changed the speculated draw"
+                self.secs_l, self.grids, self.res, self.ev_grid = secs_l, grids, res, ev
+                return
+            raise AssertionError("stale speculation: end() must have discarded it")
         secs_l, grids = [], []
         with torch.cuda.stream(self.side):
             for s in self.act:
-                secs_l.append(s._sample_secs(self.n))
+                secs_l.append(self._draw(s))
                 s.search_budget -= self.n
         for s, secs in zip(self.act, secs_l):
             grids.append(s._device_grid(secs))
         self.secs_l, self.grids = secs_l, grids
-        self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=[s._slot for s in self.act])
+        self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(self.act))
         self.ev_grid = torch.cuda.Event()
         self.ev_grid.record(self.main)
+
+    def speculate(self):
+        """Queue the NEXT iteration's grid forward behind the verification batch that ``middle()`` has just queued, BEFORE its
+        results are known (review item 4b of round 4).  Valid because the next samples depend only on what is already final:
+        ``sample_frames`` reads P and the unvisited mask (interface_searcher.py:345-358), both written by this iteration's grid
+        stage, while verification only overwrites ``score_distribution[sec]`` and ``remaining_targets`` (:407, :416-419) -- so the
+        draw is the one the sequential loop would make, from the same generator state.  If verification ends a search (its last
+        target confirmed) the speculation of the whole group is discarded in ``end()``: generator states and budgets are
+        restored, the queued forward's result is dropped (one wasted grid image, once per search).  Used when nothing else
+        would keep the detector busy between a verification batch and the next grid forward: a single live group."""
+        torch = self.torch
+        items = [s for s in self.act if s.remaining_targets and s.search_budget > 0]
+        if not items or len(items) != len(self.act):
+            return                                # an item stops on its budget after this iteration: begin() draws for the rest
+        states = [(s._rng if s._rng is not None else np.random).get_state() for s in items]
+        secs_l, grids = [], []
+        with torch.cuda.stream(self.side):
+            for s in items:
+                secs_l.append(s._sample_secs(self.n))          # NOT the public hook: a discarded draw must stay invisible
+                s.search_budget -= self.n
+        for s, secs in zip(items, secs_l):
+            grids.append(s._device_grid(secs))
+        res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(items))
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.spec = (items, secs_l, grids, res, ev, states)
+
+    def _drop_speculation(self):
+        items, _, _, res, _, states = self.spec
+        self.spec = None
+        for s, st in zip(items, states):
+            (s._rng if s._rng is not None else np.random).set_state(st)
+            s.search_budget += self.n
+            s.device_images_scored += 1           # the image did go through the detector
+        cb = getattr(self.h, "_speculation_dropped", None)       # observers of score_batch (a test recorder) drop it too
+        if cb is not None:
+            cb(res)
 
     def middle(self):
         """Wait for the grid forward; the verification batch (detector stream) and, under its shadow, the score write-back
@@ -111,7 +176,7 @@ class _Group:
         if offs[-1] > 0:
             vframes = torch.cat([s._device_verify_frames([secs_l[i][j] for j in cand_l[i]])
                                  for i, s in enumerate(act) if cand_l[i]])
-            sets = [s._slot for i, s in enumerate(act) for _ in cand_l[i]]
+            sets = None if self.solo else [s._slot for i, s in enumerate(act) for _ in cand_l[i]]
             vres = h.score_batch(vframes, 1, 1, image_sets=sets)
             ev = torch.cuda.Event()
             ev.record(self.main)
@@ -122,6 +187,8 @@ class _Group:
                 s.device_images_scored += 1
                 if s.keep_visual_history:
                     imgs, dets = h.annotated_batch(self.grids[i].unsqueeze(0), res, i, 1)
+                    if self.solo:
+                        h.detections_inbatch = dets                 # refreshed per call, like the reference's (B.13)
                     s.image_grid_iters.append([imgs[0]])
                     s.detect_annotot_iters.append([imgs[0]])
                     s.detect_bbox_iters.append(dets)
@@ -140,6 +207,8 @@ class _Group:
     def end(self):
         """Wait for the verification batch; the sequential ``remaining_targets`` replay and its score overwrites."""
         if self.pending is None:
+            if self.spec is not None:             # (defensive: a speculation always follows a middle())
+                self._drop_speculation()
             return
         torch = self.torch
         vres, vframes, ev, cand_l, offs, names_l = self.pending
@@ -158,7 +227,12 @@ class _Group:
         for s in act:
             s.iterations += 1
         self.res = self.grids = None
-        self.act = self._active()
+        if self.spec is not None:
+            # the speculation was made with this iteration's budget already spent, so "still active" is the same test it used
+            still = [s for s in self.spec[0] if s.remaining_targets]
+            if len(still) != len(self.spec[0]):
+                self._drop_speculation()
+        self.act = self._active() if self.spec is None else list(self.spec[0])
 
     def finish(self):
         torch = self.torch
@@ -210,7 +284,28 @@ def search_lockstep_groups(groups: Sequence[Sequence[TStarSearcher]]) -> List[Li
                 continue
             g.begin()
             g.middle()
+            if len(live) == 1 and _SPECULATE:
+                g.speculate()          # nothing else would fill the detector between this group's verification and its next grid forward
     return [g.finish() for g in gs]
+
+
+def search_solo(searcher: TStarSearcher) -> Tuple[np.ndarray, list]:
+    """``TStarSearcher.search()`` of ONE searcher on the fast path: the same statements in the same order as the sequential loop
+    (interface_searcher.py:444-491 of the reference), cut at the two points where the host waits for the detector, with the state
+    kernels on the side stream and the next iteration's grid forward queued speculatively behind each verification batch
+    (``_Group.speculate``).  The searcher keeps its own query-set slot 0 and its public ``sample_frames`` hook."""
+    import torch
+    g = _Group([searcher], 0, torch)
+    g.solo = True
+    searcher._slot = 0
+    g.install()
+    while g.act:
+        g.begin()
+        g.middle()
+        if _SPECULATE:
+            g.speculate()
+        g.end()
+    return g.finish()[0]
 
 
 def search_lockstep(searchers: Sequence[TStarSearcher]) -> List[Tuple[np.ndarray, list]]:
