@@ -15,7 +15,7 @@ step is its own (video, question) item -- a distinct procedural video, one of fo
 item i on rank i % N (weak scaling, no data-path collective), and the final keyframe indices are
 all-gathered once inside the timed region through the library's own RCCL entry point
 (tstar_allgather_i32).  --workload haystack32 runs exactly configs[2] (32 items).  Within a rank, items advance in
-lock-step groups of --lockstep (default 4): iteration t of every item of the group shares one
+lock-step groups of --lockstep (default 8): iteration t of every item of the group shares one
 detector batch, each image scored against its own question (tstar_amd/lockstep.py); results are
 bit-identical to one-by-one searches.
 
@@ -53,7 +53,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps = searched videos per rank; default 8 (two lock-step groups of 4), 48 with --heuristic yolo (two groups of 24)")
+                    help="timed steps = searched videos per rank; default 16 (two lock-step groups of 8), 48 with --heuristic yolo (two groups of 24)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=16, help="grid side g (g*g frames per iteration)")
     ap.add_argument("--max-batch", type=int, default=256, help="detector images per forward chunk")
@@ -80,8 +80,9 @@ def parse():
                          "launches inflate per-launch durations, so the roofline leg is reported at 1")
     ap.add_argument("--lockstep", type=int, default=0,
                     help="independent (video, question) items advanced in lock-step per detector batch "
-                         "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time; default 4 "
-                         "with the OWL-ViT backend, 24 with YOLO-World (its grid forwards run at B = the group size: 57 TFLOP/s at 8, "
+                         "(tstar_amd.lockstep; results identical to one-by-one searches); 1 = one at a time; default 8 "
+                         "with the OWL-ViT backend (round 5, f32x3 mode: 11.70 k frames/s against 11.51 k at 4 in a same-box sweep, "
+                         "profiles/r05_owl_pipeline_sweep.log; rounds 1-4 used 4), 24 with YOLO-World (its grid forwards run at B = the group size: 57 TFLOP/s at 8, "
                          "72 at 16, 84 at 24, and an iteration's ~228 verification frames fill three full chunks of 76: 12.3 k frames/s "
                          "against 12.05 k at 16 and 12.15 k at 31 in a same-box A/B; --steps defaults to 48 there)")
     ap.add_argument("--pipeline", type=int, default=2,
@@ -119,9 +120,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget for the CPU baseline sample")
     args = ap.parse_args()
     if args.lockstep <= 0:
-        args.lockstep = 24 if args.heuristic == "yolo" else 4
+        args.lockstep = 24 if args.heuristic == "yolo" else 8
     if args.steps is None:
-        args.steps = 48 if args.heuristic == "yolo" else 8
+        args.steps = 48 if args.heuristic == "yolo" else 16
     return args
 
 

@@ -955,6 +955,10 @@ static int launch_mode(const GemmArgs& g, hipStream_t stream) {
             int big = 0;
             if (forced == 4) big = mt;
             else if (bw >= 512) big = (bw % 512) > 256 ? mt : (int)(((bw / 512) * 512) / ntw);
+            // f32x3, under one wave of wide tiles (tools/sweep_x3_cfg.py, profiles/r05_x3_cfg_sweep.log): the wide tile still wins when its
+            // blocks nearly fill the 512 slots (>= 400: fc1 at B = 8 195 -> 216, qkv at B = 10 190 -> 212 TFLOP/s) or when every block gets
+            // a CU to itself (192..256: out-proj / fc2 at B = 16 +5 / +7 %); in between (a full CU pair next to single ones) it loses
+            else if (WMODE == 4 && (bw >= 400 || (bw >= 192 && bw <= 256))) big = mt;
             const bool fits32 = ((long long)(g.M + g.M / (g.patch_np > 0 ? g.patch_np : g.M) + 1) * g.ldc) < (1ll << 32);   // the wide epilogue's offsets
             if (big > 0 && fits32) {
                 GemmArgs h = g;
