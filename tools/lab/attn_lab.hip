@@ -13,7 +13,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
-#define TSTAR_ATTN_X3_STANDALONE 1
+#define TSTAR_ATTN_X3_LAB 1          // also compile the plane-tile + LDS-DMA form (not adopted by the library)
 #include "../../tstar_amd/csrc/attention_x3.h"
 
 static void attn_ref(const std::vector<float>& qkv, std::vector<double>& out, int B, int T, int heads) {
@@ -61,14 +61,21 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dq, qkv.size() * 4)); CK(hipMalloc(&dout, ref.size() * 4));
         CK(hipMemcpy(dq, qkv.data(), qkv.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemset(dout, 0xFF, ref.size() * 4));
-        if (tstar::attention_x3_launch(dq, dout, c.B, c.T, c.heads, 0) != 0) { printf("launch failed\n"); return 1; }
-        CK(hipDeviceSynchronize());
-        std::vector<float> o(ref.size());
-        CK(hipMemcpy(o.data(), dout, o.size() * 4, hipMemcpyDeviceToHost));
-        double maxe = 0, se = 0; bool nan = false;
-        for (size_t i = 0; i < o.size(); ++i) { const double e = o[i] - ref[i]; if (!(e == e)) nan = true; maxe = fmax(maxe, fabs(e)); se += e * e; }
-        printf("B=%d T=%3d heads=%d: max|err| %.3e  rms %.3e%s\n", c.B, c.T, c.heads, maxe, sqrt(se / o.size()), (nan || maxe > 5e-5) ? "   <-- WRONG" : "");
-        CK(hipFree(dq)); CK(hipFree(dout));
+        char* dpl; CK(hipMalloc(&dpl, tstar::kv_planes_bytes(c.B * c.T, c.heads)));
+        CK(hipMemset(dpl, 0xFF, tstar::kv_planes_bytes(c.B * c.T, c.heads)));
+        for (int variant = 0; variant < 2; ++variant) {
+            CK(hipMemset(dout, 0xFF, ref.size() * 4));
+            if (variant == 1 && tstar::kv_planes_launch(dq, dpl, c.B * c.T, c.heads, 0) != 0) { printf("planes launch failed\n"); return 1; }
+            if (tstar::attention_x3_launch(dq, dout, c.B, c.T, c.heads, 0, variant ? dpl : nullptr) != 0) { printf("launch failed\n"); return 1; }
+            CK(hipDeviceSynchronize());
+            std::vector<float> o(ref.size());
+            CK(hipMemcpy(o.data(), dout, o.size() * 4, hipMemcpyDeviceToHost));
+            double maxe = 0, se = 0; bool nan = false;
+            for (size_t i = 0; i < o.size(); ++i) { const double e = o[i] - ref[i]; if (!(e == e)) nan = true; maxe = fmax(maxe, fabs(e)); se += e * e; }
+            printf("B=%d T=%3d heads=%d %s: max|err| %.3e  rms %.3e%s\n", c.B, c.T, c.heads, variant ? "plane tiles + LDS-DMA" : "in-kernel staging    ", maxe,
+                   sqrt(se / o.size()), (nan || maxe > 5e-5) ? "   <-- WRONG" : "");
+        }
+        CK(hipFree(dq)); CK(hipFree(dout)); CK(hipFree(dpl));
     }
     // ---- speed at the bench shape
     const int B = argc > 1 ? atoi(argv[1]) : 256, T = 577, heads = 12, D = heads * 64;
@@ -79,14 +86,25 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dq, qkv.data(), qkv.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double fl = 4.0 * B * heads * (double)T * T * 64;
-    for (int rep = 0; rep < 3; ++rep) {
-        for (int i = 0; i < 2; ++i) tstar::attention_x3_launch(dq, dout, B, T, heads, 0);
+    char* dpl; CK(hipMalloc(&dpl, tstar::kv_planes_bytes(B * T, heads)));
+    tstar::kv_planes_launch(dq, dpl, B * T, heads, 0);
+    for (int rep = 0; rep < 6; ++rep) {
+        const char* pl = (rep & 1) ? dpl : nullptr;
+        for (int i = 0; i < 2; ++i) tstar::attention_x3_launch(dq, dout, B, T, heads, 0, pl);
         CK(hipEventRecord(e0));
         const int it = 5;
-        for (int i = 0; i < it; ++i) tstar::attention_x3_launch(dq, dout, B, T, heads, 0);
+        for (int i = 0; i < it; ++i) tstar::attention_x3_launch(dq, dout, B, T, heads, 0, pl);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
-        printf("attention_x3 B=%d T=%d heads=%d: %.3f ms  %.1f TFLOP/s algorithmic  %.0f executed (x6)\n", B, T, heads, ms, fl / ms / 1e9, 6 * fl / ms / 1e9);
+        printf("attention_x3 %s B=%d T=%d heads=%d: %.3f ms  %.1f TFLOP/s algorithmic  %.0f executed (x6)\n", pl ? "plane tiles + LDS-DMA" : "in-kernel staging    ",
+               B, T, heads, ms, fl / ms / 1e9, 6 * fl / ms / 1e9);
+    }
+    {   // the stand-alone plane pass, for scale (inside the model the qkv GEMM's epilogue writes the tiles)
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 5; ++i) tstar::kv_planes_launch(dq, dpl, B * T, heads, 0);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("kv_planes_kernel (stand-alone split pass): %.3f ms\n", ms / 5);
     }
     return 0;
 }

@@ -415,6 +415,173 @@ __global__ __launch_bounds__(256, MINW) void gemm_x3_v2(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// two-term mode (bf16 weights = ONE exact plane, activations as two round-to-nearest bf16 terms: BASELINE configs[4]) on the same
+// per-wave pipeline: weight fragments global -> VGPR in TWO slot sets (a fragment is re-loaded two steps ahead right after its last
+// product: 24+ MFMAs of lead at 16 MFMAs per step), a1 single- / a0 double-buffered, staging pieces in the first step of a tile.
+// Weight stream layout: [n-tile][step][lane][8 bf16] (1 KB per fragment).
+__device__ __forceinline__ void split2_rn2(float x0, float x1, unsigned (&o)[2]) {
+    f32x2 x; x[0] = x0; x[1] = x1;
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+    o[0] = hb;
+    f32x2 r; r[0] = x0 - __uint_as_float(hb << 16); r[1] = x1 - __uint_as_float(hb & 0xFFFF0000u);
+    o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
+template <int TM, int TN, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_w2_v2(const float* __restrict__ A, const char* __restrict__ Wp,
+                                                        float* __restrict__ C, int M, int N, int K) {
+    static_assert(TN % 2 == 0, "column tiles go in pairs");
+    ClockProbe probe;
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, BK = 32;
+    constexpr int A_T = BM * 64, BUF = 2 * A_T;
+    constexpr int NA = BM / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt = N / BN, mt = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int c4 = t & 7, r0 = t >> 3;
+    unsigned aoff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { int ar = m0 + r0 + 32 * i; ar = ar < M ? ar : M - 1; aoff[i] = (unsigned)(ar - m0) * (unsigned)K * 4u + c4 * 16; }
+    const char* abase = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+    const int nsteps = K / 16, nk = K / BK;
+    const char* wrow = Wp + (size_t)((n0 >> 5) + wn * TN) * nsteps * 1024;
+    const int voff = lane * 16;
+    const int rd0 = (wm * TM * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
+    const int rd1 = rd0 ^ 32;
+    const int wr0 = r0 * 64 + (((c4 >> 1) ^ ((r0 >> 2) & 3)) << 4) + (c4 & 1) * 8;
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wrow), 0, 0x7fffffff, 0x00020000);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[NA];
+    u32x4 w[2][TN];                 // w[set][j]: step parity -> set
+    bf16x8 a0[2][TM], a1[TM];
+    unsigned sp[2][2];
+
+    auto gloadA = [&](int kt) __attribute__((always_inline)) {
+        kt = kt < nk ? kt : nk - 1;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, (int)aoff[i], kt * (BK * 4), 0));
+    };
+    auto wload = [&](auto SET, auto J, int g) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value, j = decltype(J)::value;
+        g = g < nsteps ? g : nsteps - 1;
+        w[st][j] = __builtin_amdgcn_raw_buffer_load_b128(rw_rsrc, voff, (j * nsteps + g) * 1024, 0);
+    };
+    auto rdA = [&](const char* base, int off, int plane, int i) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(base + off + plane * A_T + i * 2048);
+    };
+    auto stage_piece = [&](auto P, char* wbase) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value, i = p >> 1, hf = p & 1;
+        split2_rn2(ra[i][2 * hf], ra[i][2 * hf + 1], sp[hf]);
+        if constexpr (hf == 1) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                u32x2 v; v[0] = sp[0][k]; v[1] = sp[1][k];
+                *reinterpret_cast<u32x2*>(wbase + wr0 + k * A_T + i * 2048) = v;
+            }
+        }
+    };
+    auto mf = [&](const bf16x8& a, const u32x4& b, f32x16& c) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    auto step = [&](auto SS, const char* rbase, int roff, char* wbase, int g, int ktload) __attribute__((always_inline)) {
+        constexpr int S = decltype(SS)::value;          // step inside the tile = weight slot set = a0 set
+        constexpr int NPIECE = NA * 2, GP = TN / 2, NG = 2 * GP, PPG = (NPIECE + 1 + NG - 1) / NG;
+        auto after_group = [&](auto G) __attribute__((always_inline)) {
+            constexpr int gi = decltype(G)::value;
+            if constexpr (S == 0) {
+                [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
+                    ([&] {
+                        constexpr int p = gi * PPG + Q;
+                        if constexpr (p < NPIECE) stage_piece(std::integral_constant<int, p>{}, wbase);
+                        if constexpr (p == NPIECE) gloadA(ktload);
+                    }(), ...);
+                }(std::make_integer_sequence<int, PPG>{});
+            }
+            if constexpr (gi == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[S ^ 1][i] = rdA(rbase, roff, 0, i);
+            }
+            FENCE();
+        };
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = 2 * JP;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a1[i], w[S][j0 + jj], acc[i][j0 + jj]);
+                after_group(std::integral_constant<int, 2 * JP + 0>{});
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[S][j0 + jj], acc[i][j0 + jj]);
+                wload(std::integral_constant<int, S>{}, std::integral_constant<int, j0>{}, g + 2);
+                wload(std::integral_constant<int, S>{}, std::integral_constant<int, j0 + 1>{}, g + 2);
+                if constexpr (JP == GP - 1) {               // a1's last product of the step has issued
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a1[i] = rdA(rbase, roff, 1, i);
+                }
+                after_group(std::integral_constant<int, 2 * JP + 1>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+    };
+    // NOTE a1 of the next step is read after the LAST pair's a0 products were issued, i.e. at the very end of the step: its first use is
+    // the next step's first MFMA -- exposed; see the measured result before refining (a1 double-buffered costs TM * 4 registers).
+
+    gloadA(0);
+    [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
+        ((wload(std::integral_constant<int, 0>{}, std::integral_constant<int, J>{}, 0),
+          wload(std::integral_constant<int, 1>{}, std::integral_constant<int, J>{}, 1)), ...);
+    }(std::make_integer_sequence<int, TN>{});
+    [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
+        (stage_piece(std::integral_constant<int, P>{}, smem), ...);
+    }(std::make_integer_sequence<int, NA * 2>{});
+    gloadA(1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { a0[0][i] = rdA(smem, rd0, 0, i); a1[i] = rdA(smem, rd0, 1, i); }
+    __builtin_amdgcn_s_setprio(1);
+    FENCE();
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * BUF;
+        char* nxt = smem + ((kt + 1) & 1) * BUF;
+        step(std::integral_constant<int, 0>{}, cur, rd1, nxt, 2 * kt, kt + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        FENCE();
+        step(std::integral_constant<int, 1>{}, nxt, rd0, nxt, 2 * kt + 1, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    }
+    probe.done();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 static unsigned short f2bf_rn(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
 static float bf2f(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
 
@@ -529,6 +696,64 @@ int main(int argc, char** argv) {
                 fflush(stdout);
             }
         printf("\n");
+    }
+    // ---- two-term mode: correctness (vs float64 on bf16-rounded weights) and speed
+    {
+        auto pack_w1 = [&](const float* W, int N, int K, std::vector<unsigned short>& out) {
+            const int ns = K / 16;
+            out.assign((size_t)(N / 32) * ns * 512, 0);
+            for (int n = 0; n < N; ++n)
+                for (int k = 0; k < K; ++k)
+                    out[(((size_t)(n / 32) * ns + k / 16) * 64 + ((k % 16) / 8) * 32 + n % 32) * 8 + k % 8] = f2bf_rn(W[(size_t)n * K + k]);
+        };
+        auto run_w2 = [&](auto kern, int BM, int BN, const float* a, float* c, int m, int n, int k, int iters) {
+            const int lds = 2 * 2 * BM * 64;
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            const int nwg = ((m + BM - 1) / BM) * (n / BN);
+            if (iters == 0) { hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, 0, a, Wp, c, m, n, k); CK(hipDeviceSynchronize()); return 0.f; }
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, 0, a, Wp, c, m, n, k);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, 0, a, Wp, c, m, n, k);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            return ms / iters;
+        };
+        if (!only) for (int k : {64, 768, 3072}) {
+            const int m = 300, n = 256;
+            std::vector<float> a((size_t)m * k), w((size_t)n * k);
+            for (auto& v : a) v = gauss();
+            for (auto& v : w) v = bf2f(f2bf_rn(gauss() * 0.03f));
+            std::vector<double> ref((size_t)m * n);
+            for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) {
+                double r = 0;
+                for (int kk = 0; kk < k; ++kk) r += (double)a[(size_t)i * k + kk] * (double)w[(size_t)j * k + kk];
+                ref[(size_t)i * n + j] = r;
+            }
+            float* a2; CK(hipMalloc(&a2, a.size() * 4)); CK(hipMemcpy(a2, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+            pack_w1(w.data(), n, k, pk); CK(hipMemcpy(Wp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+            std::vector<float> hC((size_t)m * n);
+            CK(hipMemset(C, 0xFF, hC.size() * 4));
+            run_w2(gemm_w2_v2<2, 4, 2>, 128, 256, a2, C, m, n, k, 0);
+            CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+            double maxe = 0, se = 0;
+            for (size_t i = 0; i < hC.size(); ++i) { const double e = hC[i] - ref[i]; maxe = fmax(maxe, fabs(e)); se += e * e; }
+            printf("  K=%4d two-term v2 128x256                      max|err| %.3e  rms err %.3e%s\n", k, maxe, sqrt(se / hC.size()), (maxe < 1e-3 && maxe == maxe) ? "" : "   <-- WRONG");
+            CK(hipFree(a2));
+        }
+        for (auto sh : shapes) {
+            const double fl = 2.0 * M * sh.N * sh.K;
+            pack_w1(hW.data(), sh.N, sh.K, pk); CK(hipMemcpy(Wp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+            for (int rep = 0; rep < 2; ++rep) {
+                unsigned long long z[2] = {0, 0}, c[2];
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z)));
+                const float ms = run_w2(gemm_w2_v2<2, 4, 2>, 128, 256, A, C, M, sh.N, sh.K, 5);
+                CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_clk), sizeof(c)));
+                const double ghz = c[1] ? (double)c[0] / (double)c[1] * 0.1 : 0.0;
+                printf("N=%4d K=%4d two-term v2 128x256 (W global -> VGPR, 2 slot sets) %7.3f ms  %6.1f TFLOP/s algorithmic  %6.0f executed  %.2f GHz\n", sh.N, sh.K, ms,
+                       fl / ms / 1e9, 2 * fl / ms / 1e9, ghz);
+            }
+        }
     }
     return 0;
 }

@@ -77,8 +77,14 @@ __device__ __forceinline__ f32x16 mfma(const bf16x8 a, const u32x4 b, const f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int heads,
-                                                              int qtiles) {
+// PLANES = false: K / V come from the f32 qkv rows and are split while they are staged (any caller: tstar_attention_x3).
+// PLANES = true: the qkv GEMM's epilogue has already written them as plane tiles (kv_plane_tile() below: one 24-KB LDS image per
+// GLOBAL 32-row tile of the token matrix and head) and the kernel copies them with the LDS-DMA engine (global_load_lds_dwordx4:
+// no staging registers, no split, no LDS stores in the loop -- the split happens ONCE per K / V element instead of once per
+// query block); key tiles are then the global tiles that overlap the image's rows, masked at both ends.
+template <bool PLANES>
+__global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __restrict__ qkv, const char* __restrict__ planes,
+                                                              float* __restrict__ out, int T, int heads, int qtiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kbuf = smem;
     char* const vbuf = smem + NKB * KBUF;
@@ -134,8 +140,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
         vwr[e] = v_off(4 * vdq + e, pos >> 4) + (pos & 15);
     }
 
-    const bool tail_key = (T % KB) == 1;
-    const int nkb = tail_key ? T / KB : (T + KB - 1) / KB;
+    const int R0 = b * T;                                                    // first global row of the image (PLANES: tiles are global)
+    const int kt0 = R0 >> 5;
+    const bool tail_key = !PLANES && (T % KB) == 1;
+    const int nkb = PLANES ? ((R0 + T - 1) >> 5) - kt0 + 1 : (tail_key ? T / KB : (T + KB - 1) / KB);
 
     f32x4 rk[2], rv[2];
     auto gload = [&](int kb) __attribute__((always_inline)) {
@@ -176,6 +184,27 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
         }(std::make_integer_sequence<int, 8>{});
     };
 
+    // PLANES: tile kb of this image = global tile kt0 + kb; its 24 one-KB chunks (12 K, 12 V^T) are copied by the four waves, six each,
+    // lane-linear (the image in global memory IS the swizzled LDS image).  M0 carries the LDS destination (saved / restored inside
+    // the statement: it is compiler-reserved); completion is counted by the issuing wave (s_waitcnt vmcnt) before the tile barrier.
+    auto dma = [&](int kb) __attribute__((always_inline)) {
+        if constexpr (PLANES) {
+            if (kb < nkb) {
+                const char* src = planes + ((size_t)(kt0 + kb) * heads + head) * (size_t)(KBUF + VBUF) + lane * 16;
+                const unsigned kdst = (unsigned)(size_t)(kbuf + (kb & 1) * KBUF), vdst = (unsigned)(size_t)(vbuf + (kb % NVB) * VBUF);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int chunk = wave + 4 * c;                          // 0..23, wave-uniform
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(chunk < 12 ? kdst + chunk * 1024 : vdst + (chunk - 12) * 1024);
+                    const char* g = src + chunk * 1024;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+                }
+            }
+        }
+    };
+
     // fragment reads: per-lane offsets formed once (the XOR swizzles), planes / d halves as immediates
     int kro[4], vro[2];
 #pragma unroll
@@ -200,7 +229,11 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
     bf16x8 vf[3][2];                                                         // V^T fragments of the current ks: [term][dt]
 
     // ---- prologue: tiles 0 and 1 into LDS, tile 2 into the staging registers, S(0)
-    if (nkb > 0) {
+    if constexpr (PLANES) {
+        dma(0);
+        dma(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (nkb > 0) {
         gload(0);
         stage_all(0);
         gload(1);
@@ -223,7 +256,13 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
     auto soft_piece = [&](auto P, auto MASK, f32x16& sc_, int kb) __attribute__((always_inline)) {
         constexpr int p = decltype(P)::value;
         if constexpr (p == 0) {
-            if (decltype(MASK)::value && !tail_key && kb == nkb - 1) {                               // a partial last tile: mask the keys past T
+            if constexpr (PLANES) {
+                if (decltype(MASK)::value) {                                 // the first / last global tile also holds rows of the neighbouring images
+                    const int row0 = (kt0 + kb) * KB + 4 * h - R0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc_[r] = (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) < (unsigned)T ? sc_[r] : -INFINITY;
+                }
+            } else if (decltype(MASK)::value && !tail_key && kb == nkb - 1) {                               // a partial last tile: mask the keys past T
                 const int key0 = kb * KB + 4 * h;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc_[r] = (key0 + (r & 3) + 8 * (r >> 2)) < T ? sc_[r] : -INFINITY;
@@ -308,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
         AX3_FENCE();
         auto extra = [&](auto G) __attribute__((always_inline)) {
             constexpr int g = decltype(G)::value;                            // MFMA group 0..11 of this phase
-            if constexpr (dost) {
+            if constexpr (dost && !PLANES) {
                 if constexpr (g < 8) stage_piece(std::integral_constant<int, g>{}, kd, vd);
                 if constexpr (g == 8) gload(kb + 3);
             }
@@ -337,34 +376,53 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
     };
 
     auto tile_barrier = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (PLANES) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's DMA pieces (issued a tile ago) + its LDS reads
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         AX3_FENCE();
+    };
+    // one iteration of the generic (peeled) form: roles of the two score registers by the parity of kb, S(kb + 1) only if it exists
+    auto iteration = [&](int kb) __attribute__((always_inline)) {
+        dma(kb + 2);
+        if (kb & 1) { if (kb + 1 < nkb) phase_a(std::true_type{}, std::true_type{}, s1_, s0_, kb); else phase_a(std::false_type{}, std::true_type{}, s1_, s0_, kb); }
+        else { if (kb + 1 < nkb) phase_a(std::true_type{}, std::true_type{}, s0_, s1_, kb); else phase_a(std::false_type{}, std::true_type{}, s0_, s1_, kb); }
+        if (kb + 2 < nkb) phase_b(std::true_type{}, kb); else phase_b(std::false_type{}, kb);
+        tile_barrier();
     };
     if (wave_active) {
         __builtin_amdgcn_s_setprio(1);
         int kb = 0;
-        // full iterations in pairs: S(kb + 1) and the staging of tile kb + 2 both exist (kb + 2 < nkb for both halves)
-        for (; kb + 3 < nkb; kb += 2) {
-            phase_a(std::true_type{}, std::false_type{}, s0_, s1_, kb);
-            phase_b(std::true_type{}, kb);
-            tile_barrier();
-            phase_a(std::true_type{}, std::false_type{}, s1_, s0_, kb + 1);
-            phase_b(std::true_type{}, kb + 1);
-            tile_barrier();
+        if constexpr (PLANES) {
+            if (nkb > 0) { iteration(0); kb = 1; }                           // the first global tile is masked: peeled
+            // full, unmasked iterations in pairs (kb odd): neither is the last tile
+            for (; kb + 2 < nkb; kb += 2) {
+                dma(kb + 2);
+                phase_a(std::true_type{}, std::false_type{}, s1_, s0_, kb);
+                phase_b(std::true_type{}, kb);
+                tile_barrier();
+                dma(kb + 3);
+                phase_a(std::true_type{}, std::false_type{}, s0_, s1_, kb + 1);
+                phase_b(std::true_type{}, kb + 1);
+                tile_barrier();
+            }
+        } else {
+            // full iterations in pairs: S(kb + 1) and the staging of tile kb + 2 both exist (kb + 2 < nkb for both halves)
+            for (; kb + 3 < nkb; kb += 2) {
+                phase_a(std::true_type{}, std::false_type{}, s0_, s1_, kb);
+                phase_b(std::true_type{}, kb);
+                tile_barrier();
+                phase_a(std::true_type{}, std::false_type{}, s1_, s0_, kb + 1);
+                phase_b(std::true_type{}, kb + 1);
+                tile_barrier();
+            }
         }
-        // the last two or three tiles (kb is even here)
-        for (; kb < nkb; ++kb) {
-            if (kb & 1) { if (kb + 1 < nkb) phase_a(std::true_type{}, std::true_type{}, s1_, s0_, kb); else phase_a(std::false_type{}, std::true_type{}, s1_, s0_, kb); }
-            else { if (kb + 1 < nkb) phase_a(std::true_type{}, std::true_type{}, s0_, s1_, kb); else phase_a(std::false_type{}, std::true_type{}, s0_, s1_, kb); }
-            if (kb + 2 < nkb) phase_b(std::true_type{}, kb); else phase_b(std::false_type{}, kb);
-            tile_barrier();
-        }
+        for (; kb < nkb; ++kb) iteration(kb);                                // the last one to three tiles
         __builtin_amdgcn_s_setprio(0);
     } else {
         // a wave without queries (the last query block of a head) only stages
         for (int kb = 0; kb < nkb; ++kb) {
-            if (kb + 2 < nkb) { stage_all(kb + 2); gload(kb + 3); }
+            if constexpr (PLANES) dma(kb + 2);
+            else if (kb + 2 < nkb) { stage_all(kb + 2); gload(kb + 3); }
             tile_barrier();
         }
     }
@@ -419,18 +477,90 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
 
 }  // namespace ax3
 
-// launches the kernel on `s`; returns 0, or a hipError_t value
-inline int attention_x3_launch(const float* qkv, float* out, int B, int T, int heads, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ax3::attention_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 ax3::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
+// One plane tile: K planes [3][32 keys][64 d] then V^T planes [3][64 d][32 keys], bfloat16, in the swizzled LDS layout (k_off / v_off /
+// v_keypos above) -- 24 KB per (global 32-row tile, head); tile (kt, head) starts at ((kt * heads) + head) * 24576.
+inline size_t kv_planes_bytes(int rows, int heads) { return (size_t)((rows + 31) / 32) * heads * (size_t)(ax3::KBUF + ax3::VBUF); }
+
+#ifdef TSTAR_ATTN_X3_LAB
+namespace ax3 {
+// f32 qkv rows -> plane tiles (what the qkv GEMM's epilogue writes in the f32x3 mode; this kernel is the stand-alone form for the
+// C-ABI entry / tests / the lab).  One thread per (row pair, head, 4 d): rows past `rows` are written as zeros.
+__global__ __launch_bounds__(256) void kv_planes_kernel(const float* __restrict__ qkv, char* __restrict__ planes, int rows, int heads) {
+    const int D = heads * HD, D3 = 3 * D;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int dq = (int)(gid % 16), head = (int)((gid / 16) % heads);
+    const size_t rp = gid / (16 * (size_t)heads);                            // row pair
+    const int row = (int)(rp * 2);
+    if (row >= ((rows + 31) / 32) * 32) return;
+    const int kt = row >> 5, key = row & 31;
+    char* tile = planes + ((size_t)kt * heads + head) * (size_t)(KBUF + VBUF);
+    f32x4 kx[2], vx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (row + i < rows) {
+            kx[i] = *reinterpret_cast<const f32x4*>(qkv + (size_t)(row + i) * D3 + D + head * HD + dq * 4);
+            vx[i] = *reinterpret_cast<const f32x4*>(qkv + (size_t)(row + i) * D3 + 2 * D + head * HD + dq * 4);
+        } else {
+            kx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                             // K: [key][d], d contiguous
+        unsigned o0[3], o1[3];
+        split2_rn3(kx[i][0], kx[i][1], o0);
+        split2_rn3(kx[i][2], kx[i][3], o1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u32x2 v; v[0] = o0[k]; v[1] = o1[k];
+            *reinterpret_cast<u32x2*>(tile + k * KP + k_off(key + i, dq >> 1) + (dq & 1) * 8) = v;
+        }
+    }
+    const int pos = v_keypos(key);                                            // V^T: [d][key], the pair (key, key + 1) stays adjacent
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned o[3];
+        split2_rn3(vx[0][e], vx[1][e], o);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<unsigned*>(tile + KBUF + k * VP + v_off(4 * dq + e, pos >> 4) + (pos & 15)) = o[k];
+    }
+}
+}  // namespace ax3
+
+// launches the kernel on `s`; returns 0, or a hipError_t value.  `planes` = nullptr: K / V are split from the f32 rows in the kernel
+// (the library's form).  The plane-tile + LDS-DMA form is compiled for the lab only (TSTAR_ATTN_X3_LAB): measured at the bench shape
+// it is 7 % faster (159.7 vs 148.8 TFLOP/s, profiles/r05_attention_x3_planes_dma_lab.log) -- about 1 % of a step, less than what
+// writing the tiles from the qkv GEMM's epilogue would cost -- so the library does not use it.
+inline int attention_x3_launch(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, const char* planes = nullptr) {
+    static bool attr[2] = {false, false};
     const int qtiles = (T + 127) / 128;
-    hipLaunchKernelGGL(ax3::attention_x3_kernel, dim3(B * heads * qtiles), dim3(256), ax3::LDS_BYTES, s, qkv, out, T, heads, qtiles);
+#ifdef TSTAR_ATTN_X3_LAB
+    if (planes) {
+        if (!attr[1]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ax3::attention_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ax3::LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr[1] = true;
+        }
+        hipLaunchKernelGGL(ax3::attention_x3_kernel<true>, dim3(B * heads * qtiles), dim3(256), ax3::LDS_BYTES, s, qkv, planes, out, T, heads, qtiles);
+        return (int)hipGetLastError();
+    }
+#endif
+    if (planes) return (int)hipErrorInvalidValue;
+    if (!attr[0]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ax3::attention_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ax3::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr[0] = true;
+    }
+    hipLaunchKernelGGL(ax3::attention_x3_kernel<false>, dim3(B * heads * qtiles), dim3(256), ax3::LDS_BYTES, s, qkv, planes, out, T, heads, qtiles);
     return (int)hipGetLastError();
 }
+
+// f32 qkv [rows, 3 * heads * 64] -> plane tiles (kv_planes_bytes(rows, heads) bytes)
+inline int kv_planes_launch(const float* qkv, char* planes, int rows, int heads, hipStream_t s) {
+    const size_t n = (size_t)((rows + 31) / 32) * 16 * 16 * heads;           // (row pairs of whole tiles) x heads x 16 float4 columns
+    hipLaunchKernelGGL(ax3::kv_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, planes, rows, heads);
+    return (int)hipGetLastError();
+}
+#endif
 
 }  // namespace tstar
