@@ -526,6 +526,7 @@ __global__ __launch_bounds__(256) void kv_planes_kernel(const float* __restrict_
     }
 }
 }  // namespace ax3
+#endif
 
 // launches the kernel on `s`; returns 0, or a hipError_t value.  `planes` = nullptr: K / V are split from the f32 rows in the kernel
 // (the library's form).  The plane-tile + LDS-DMA form is compiled for the lab only (TSTAR_ATTN_X3_LAB): measured at the bench shape
@@ -555,6 +556,7 @@ inline int attention_x3_launch(const float* qkv, float* out, int B, int T, int h
     return (int)hipGetLastError();
 }
 
+#ifdef TSTAR_ATTN_X3_LAB
 // f32 qkv [rows, 3 * heads * 64] -> plane tiles (kv_planes_bytes(rows, heads) bytes)
 inline int kv_planes_launch(const float* qkv, char* planes, int rows, int heads, hipStream_t s) {
     const size_t n = (size_t)((rows + 31) / 32) * 16 * 16 * heads;           // (row pairs of whole tiles) x heads x 16 float4 columns
