@@ -201,9 +201,12 @@ def grid4_record(heuristic, store, nframes, k):
             "solo_sec_per_video": t_solo, "solo_frames_per_s": solo[0][0].frames_scored / t_solo,
             "grid_calls_per_video": sum(s_.iterations for s_, _ in grp) / nv,
             "verify_calls_per_video": sum(s_.detector_calls - s_.iterations for s_, _ in grp) / nv,
-            "solo_bound": "host: the FITPACK smoothing-spline fit (sequential Fortran, grows with the number of visited frames, 63 fits per "
-                          "video) sits on the critical path between two iterations; it is the reference's own scipy call, kept for bit-exact "
-                          "sampling, and only overlaps its own iteration's verification batch"}
+            "solo_bound": "GPU kernels cover ~82-99 % of a solo search (profiles/r05_solo_grid4_gaps.txt: 643 ms of kernels in a 650 ms search; "
+                          "under the tracer the remaining idle is the host FITPACK fit of the LATE iterations, ~800 knots, 3-7 ms, outlasting the "
+                          "verification forward it overlaps); the kernels themselves run at small batch: a B = 1 grid forward (M = 577) and a "
+                          "B ~ 10 verification forward per iteration, 63 iterations, 670 detector images at ~1 ms each against 0.55 ms in the "
+                          "lock-step bench.  The next iteration's grid forward is queued speculatively behind each verification batch "
+                          "(tstar_amd.lockstep._Group.speculate: -3 %), split-K for the M = 577 launches would change bits with the batch size and is not used"}
 
 
 def cpu_baseline(args, stats):
@@ -758,7 +761,7 @@ def main():
     if args.heuristic == "yolo":
         gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel + conv_sw_kernel (implicit-GEMM convolutions, v_pk_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
         traffic, traffic_src = None, None
-        for tag in ("r04", "r03", "r02"):         # tools/collect_yolo_profiles.sh (PMC passes of this command)
+        for tag in ("r05", "r04", "r03", "r02"):  # tools/collect_yolo_profiles.sh (PMC passes of this command)
             tp = os.path.join(ROOT, "profiles", f"{tag}_yolo_pmc_conv_traffic.json")
             if os.path.isfile(tp):
                 try:

@@ -6,7 +6,10 @@ export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out
 cd /tmp
 python $ROOT/tools/solo_latency_probe.py 4 > $ROOT/gpurun_out/solo_grid4_probe.log 2>&1
-TSTAR_NATIVE_FIT=0 python $ROOT/tools/solo_latency_probe.py 4 > $ROOT/gpurun_out/solo_grid4_probe_scipy_fit.log 2>&1
+# round 5 A/Bs, same box: without the speculative next-grid forward; the plain sequential loop of rounds 1-4; the native-f32 mode
+( echo "# TSTAR_NO_SPECULATION=1"; TSTAR_NO_SPECULATION=1 python $ROOT/tools/solo_latency_probe.py 4 2>&1 | head -3
+  echo "# TSTAR_SOLO_SEQUENTIAL=1"; TSTAR_SOLO_SEQUENTIAL=1 python $ROOT/tools/solo_latency_probe.py 4 2>&1 | head -3
+  echo "# weights mode f32"; python $ROOT/tools/solo_latency_probe.py 4 0 f32 2>&1 | head -3 ) >> $ROOT/gpurun_out/solo_grid4_probe.log
 rm -rf /tmp/sg4
 rocprofv3 --kernel-trace -d /tmp/sg4 -o tr -- python $ROOT/tools/solo_latency_probe.py 4 > /dev/null 2> /tmp/sg4.err || tail -3 /tmp/sg4.err
 DB=$(find /tmp/sg4 -name '*.db' | head -1)

@@ -2,7 +2,7 @@
 statement groups of `bench.py`'s single-search latency figure, and -- under `rocprofv3 --kernel-trace` -- marker kernels
 around the search so that tools/rocpd_gaps.py --timed-region can report the GPU idle time inside it.
 
-    python tools/solo_latency_probe.py [grid] [lockstep-of-one: 0 | 1]
+    python tools/solo_latency_probe.py [grid] [lockstep-of-one: 0 | 1] [weights mode: f32x3 (default, the bench's) | f32 | ...]
 """
 import cProfile
 import io
@@ -24,7 +24,10 @@ from tstar_amd.video import synthetic_video
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 as_group = len(sys.argv) > 2 and sys.argv[2] == "1"
 lib = _lib.load()
-h = OWLInterface(synthetic_seed=0, max_batch=256, device="cuda:0")
+mode = sys.argv[3] if len(sys.argv) > 3 else "f32x3"
+h = OWLInterface(synthetic_seed=0, max_batch=256, device="cuda:0", weights_dtype=mode)
+print("weights mode", mode, "| speculation", "off" if os.environ.get("TSTAR_NO_SPECULATION") else "on", "| solo path",
+      "sequential loop" if os.environ.get("TSTAR_SOLO_SEQUENTIAL") else "lockstep.search_solo")
 store = synthetic_video(3600, 360, 640, seed=0)
 item = lambda seed: dict(store=store, targets=bench.TARGETS, cues=bench.CUES, seed=seed)
 

@@ -16,8 +16,8 @@
 //    are re-read from LDS into the registers of a plane as soon as that plane's last product of the step has issued (products
 //    ordered x0-first for that reason), the order is pinned with sched_barrier, ONE barrier per key tile.
 //  * LDS: K planes [key][d] (128-B rows, 16-B chunks XOR-swizzled by (key >> 1) & 7) double-buffered, V^T planes [d][key]
-//    (64-B rows, keys permuted so that a lane's eight keys of a step are one 16-B chunk, chunks XOR-swizzled; V is transposed while staged) triple-buffered because tile t + 2 is
-//    written while tile t is read: 60 KB per workgroup, 2 workgroups per CU (256 registers per wave).
+//    (80-B rows, keys permuted so that a lane's eight keys of a step are one 16-B chunk; V is transposed while staged) triple-buffered because tile t + 2 is
+//    written while tile t is read: 69 KB per workgroup, 2 workgroups per CU (256 registers per wave).
 //  * T = 32 n + 1 (577): the straggler key is folded in with f32 VALU ops after the loop (q rebuilt exactly from its terms).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -36,9 +36,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HD = 64, KB = 32;
-constexpr int KP = KB * 128, VP = HD * 64;              // bytes of one K plane / one V^T plane of a tile
+constexpr int VPITCH = 80;                              // bytes per V^T row: 64 of keys + 16 of padding (see v_off)
+constexpr int KP = KB * 128, VP = HD * VPITCH;          // bytes of one K plane / one V^T plane of a tile
 constexpr int KBUF = 3 * KP, VBUF = 3 * VP, NKB = 2, NVB = 3;
-constexpr int LDS_BYTES = NKB * KBUF + NVB * VBUF;      // 60 KB
+constexpr int LDS_BYTES = NKB * KBUF + NVB * VBUF;      // 69 KB
 
 #define AX3_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -67,9 +68,11 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 
 __device__ __forceinline__ int k_off(int key, int chunk) { return key * 128 + ((chunk ^ ((key >> 1) & 7)) << 4); }
 // V^T rows hold their 32 keys in the order [0-3, 8-11 | 4-7, 12-15 | 16-19, 24-27 | 20-23, 28-31]: the eight keys a lane needs for K = 16
-// step ks (4 h + {0..3} and 8 + 4 h + {0..3} of keys 16 ks ..) are ONE 16-byte chunk 2 ks + h, XOR-swizzled by (d >> 2) & 3 (a 16-lane
-// service group of ds_read_b128 reads 16 rows d: 4 (d & 3) + chunk is then a distinct slot of the 16 in a 256-B bank row)
-__device__ __forceinline__ int v_off(int d, int chunk) { return d * 64 + ((chunk ^ ((d >> 2) & 3)) << 4); }
+// step ks (4 h + {0..3} and 8 + 4 h + {0..3} of keys 16 ks ..) are ONE 16-byte chunk 2 ks + h.  Rows are 80 bytes apart: a 16-lane
+// service group of ds_read_b128 reads 16 rows d, 5 d + chunk (mod 16) is then a distinct 16-byte slot of the 256-B bank row, and the
+// staging stores of a wave (four rows 4 apart, 64 bytes each) start 80 dwords = 16 banks apart and cover all 64 banks once (with
+// 64-byte rows they were 4-way conflicts: 38 % of the LDS-busy cycles of the first form, profiles/r05_attention_x3_counters.md)
+__device__ __forceinline__ int v_off(int d, int chunk) { return d * VPITCH + (chunk << 4); }
 // byte position of key k (0..31) inside its row's un-swizzled order
 __device__ __forceinline__ int v_keypos(int k) { const int g = k >> 2; const int gp = (g & 4) | ((g & 1) << 1) | ((g >> 1) & 1); return (gp * 4 + (k & 3)) * 2; }
 
@@ -78,7 +81,7 @@ __device__ __forceinline__ f32x16 mfma(const bf16x8 a, const u32x4 b, const f32x
 }
 
 // PLANES = false: K / V come from the f32 qkv rows and are split while they are staged (any caller: tstar_attention_x3).
-// PLANES = true: the qkv GEMM's epilogue has already written them as plane tiles (kv_plane_tile() below: one 24-KB LDS image per
+// PLANES = true: the qkv GEMM's epilogue has already written them as plane tiles (kv_plane_tile() below: one 27-KB LDS image per
 // GLOBAL 32-row tile of the token matrix and head) and the kernel copies them with the LDS-DMA engine (global_load_lds_dwordx4:
 // no staging registers, no split, no LDS stores in the loop -- the split happens ONCE per K / V element instead of once per
 // query block); key tiles are then the global tiles that overlap the image's rows, masked at both ends.
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
         }(std::make_integer_sequence<int, 8>{});
     };
 
-    // PLANES: tile kb of this image = global tile kt0 + kb; its 24 one-KB chunks (12 K, 12 V^T) are copied by the four waves, six each,
+    // PLANES: tile kb of this image = global tile kt0 + kb; its one-KB chunks (12 K, 15 V^T) are copied by the four waves in turn,
     // lane-linear (the image in global memory IS the swizzled LDS image).  M0 carries the LDS destination (saved / restored inside
     // the statement: it is compiler-reserved); completion is counted by the issuing wave (s_waitcnt vmcnt) before the tile barrier.
     auto dma = [&](int kb) __attribute__((always_inline)) {
@@ -192,10 +195,13 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
             if (kb < nkb) {
                 const char* src = planes + ((size_t)(kt0 + kb) * heads + head) * (size_t)(KBUF + VBUF) + lane * 16;
                 const unsigned kdst = (unsigned)(size_t)(kbuf + (kb & 1) * KBUF), vdst = (unsigned)(size_t)(vbuf + (kb % NVB) * VBUF);
+                constexpr int NCH = (KBUF + VBUF) / 1024;                      // one-KB chunks of a tile image (K planes, then V^T planes)
+                static_assert((KBUF + VBUF) % 1024 == 0 && KBUF % 1024 == 0, "tile images are copied in 1-KB wave loads");
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const int chunk = wave + 4 * c;                          // 0..23, wave-uniform
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(chunk < 12 ? kdst + chunk * 1024 : vdst + (chunk - 12) * 1024);
+                for (int c = 0; c < (NCH + 3) / 4; ++c) {
+                    const int chunk = wave + 4 * c;                          // wave-uniform
+                    if (chunk >= NCH) break;
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(chunk < KBUF / 1024 ? kdst + chunk * 1024 : vdst + (chunk - KBUF / 1024) * 1024);
                     const char* g = src + chunk * 1024;
                     unsigned keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -210,12 +216,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
 #pragma unroll
     for (int s = 0; s < 4; ++s) kro[s] = k_off(l31, 2 * s + h);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) vro[ks] = v_off(l31, 2 * ks + h);       // (d >> 2) & 3 is the same for d and d + 32
+    for (int ks = 0; ks < 2; ++ks) vro[ks] = v_off(l31, 2 * ks + h);
     auto rdk = [&](const char* kb_, int plane, int s) __attribute__((always_inline)) {
         return *reinterpret_cast<const bf16x8*>(kb_ + plane * KP + kro[s]);
     };
     auto rdv = [&](const char* vb_, int plane, int dt, int ks) __attribute__((always_inline)) {
-        return *reinterpret_cast<const bf16x8*>(vb_ + plane * VP + dt * 2048 + vro[ks]);
+        return *reinterpret_cast<const bf16x8*>(vb_ + plane * VP + dt * (32 * VPITCH) + vro[ks]);
     };
 
     f32x16 zero16;
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
 }  // namespace ax3
 
 // One plane tile: K planes [3][32 keys][64 d] then V^T planes [3][64 d][32 keys], bfloat16, in the swizzled LDS layout (k_off / v_off /
-// v_keypos above) -- 24 KB per (global 32-row tile, head); tile (kt, head) starts at ((kt * heads) + head) * 24576.
+// v_keypos above) -- 27 KB per (global 32-row tile, head); tile (kt, head) starts at ((kt * heads) + head) * (KBUF + VBUF).
 inline size_t kv_planes_bytes(int rows, int heads) { return (size_t)((rows + 31) / 32) * heads * (size_t)(ax3::KBUF + ax3::VBUF); }
 
 #ifdef TSTAR_ATTN_X3_LAB
