@@ -750,6 +750,59 @@ def test_query_sets_are_independent():
         h.score_batch(img, 1, 1, image_sets=[1, 7])
 
 
+@pytest.mark.parametrize("thr,targets,use_global_rng", [(0.05, ["couch"], False), (0.05, ["couch", "tv"], False), (0.6, ["couch"], True)])
+def test_speculative_next_grid_equals_the_sequential_loop(monkeypatch, thr, targets, use_global_rng):
+    """Round 5: ``search()`` on the fast path runs through ``lockstep.search_solo`` and queues the NEXT iteration's samples and grid
+    forward speculatively behind each verification batch (``_Group.speculate``).  Against the plain sequential loop
+    (TSTAR_SOLO_SEQUENTIAL=1) on identically seeded searchers: same sampled seconds through the public ``sample_frames`` hook (one
+    call per executed iteration, no trace of a discarded draw), same histories, keyframes and counters, the sampler generator left
+    in the same state -- with a low threshold so that verification ENDS the search (the speculation is discarded and its draw
+    undone), with two targets (the search goes on after the first is found), and with the process-global numpy generator."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_video
+    h = OWLInterface(synthetic_seed=0, max_batch=16)
+    store = synthetic_video(700, seed=9)
+
+    def run(sequential):
+        if sequential:
+            monkeypatch.setenv("TSTAR_SOLO_SEQUENTIAL", "1")
+        else:
+            monkeypatch.delenv("TSTAR_SOLO_SEQUENTIAL", raising=False)
+        if use_global_rng:
+            np.random.seed(123)
+        rng = None if use_global_rng else np.random.RandomState(123)
+        s = TStarSearcher(store, h, list(targets), ["chair"], search_nframes=4, image_grid_shape=(3, 3), search_budget=0.2,
+                          confidence_threshold=thr, rng=rng, keep_visual_history=False)
+        rec = _Recorder(h)
+        log = []
+        orig = s.sample_frames
+        s.sample_frames = lambda num: (lambda r: (log.append(list(r[0])), r)[1])(orig(num))
+        try:
+            frames, ts = s.search()
+        finally:
+            h.score_batch = rec._orig
+            if hasattr(h, "_speculation_dropped"):
+                del h._speculation_dropped
+        after = (np.random if use_global_rng else rng).random_sample(3).tolist()       # the generator's state after the search
+        return dict(s=s, log=log, ts=list(ts), frames=frames, after=after, calls=[(c["rows"], c["conf"].shape[0]) for c in rec.calls])
+
+    spec, seq = run(False), run(True)
+    assert spec["log"] == seq["log"] and len(spec["log"]) == spec["s"].iterations
+    assert spec["ts"] == seq["ts"] and np.array_equal(spec["frames"], seq["frames"])
+    assert spec["after"] == seq["after"]
+    assert spec["calls"] == seq["calls"]                                  # no trace of a discarded speculative forward
+    a, b = spec["s"], seq["s"]
+    assert a.Score_history == b.Score_history and a.P_history == b.P_history and a.non_visiting_history == b.non_visiting_history
+    assert np.array_equal(a.score_distribution, b.score_distribution)
+    assert (a.iterations, a.frames_scored, a.detector_calls, a.remaining_targets, a.search_budget) == \
+           (b.iterations, b.frames_scored, b.detector_calls, b.remaining_targets, b.search_budget)
+    ended_by_target = not a.remaining_targets
+    if thr < 0.1:
+        assert ended_by_target                                            # the case under test: verification ended the search
+        assert a.device_images_scored == b.device_images_scored + (1 if a.search_budget > 0 else 0)     # the one wasted grid image is counted
+
+
 def test_reference_style_manual_loop_equals_search():
     """Drive the searcher through its PUBLIC methods in the order and with the keywords the reference's own
     ``search()`` body uses (:444-491): ``sample_frames`` -> ``create_image_grid`` -> ``score_image_grids`` (host image,

@@ -610,3 +610,33 @@ def test_spline_worker_count_follows_the_affinity_mask(monkeypatch):
         assert workers(mask, cpus, ranks) * ranks <= max(ranks, mask // 2)
     monkeypatch.setenv("TSTAR_SPLINE_WORKERS", "3")
     assert SP.default_workers() == 3
+
+
+def test_bench_self_spawn_command(monkeypatch):
+    """`python bench.py --gpus N` typed without a launcher (WORLD_SIZE unset) starts its own ranks: the command is the driver's
+    (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1, the user's flags passed through), launcher variables of
+    an enclosing job do not leak in, and with fewer visible GPUs than ranks the collectives fall back to gloo."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = list(cmd), dict(env)
+        return subprocess.CompletedProcess(cmd, 0)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.setenv("RANK", "7")
+    monkeypatch.setenv("MASTER_PORT", "1")
+    monkeypatch.delenv("TSTAR_BENCH_BACKEND", raising=False)
+    assert bench.self_spawn(4) == 0
+    cmd, env = seen["cmd"], seen["env"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert "RANK" not in env and "MASTER_PORT" not in env and env["MASTER_ADDR"] == "127.0.0.1"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    import torch
+    if torch.cuda.device_count() < 4:
+        assert env["TSTAR_BENCH_BACKEND"] == "gloo"

@@ -170,19 +170,13 @@ class OWLInterface(HeuristicInterface):
         """Install a question's queries in slot 1..63 WITHOUT touching ``self.texts`` (slot 0 is what
         ``reparameterize_object_list`` manages).  Several (video, question) items can then be scored in
         one batch, each image against its own slot.  Returns the texts list of the slot."""
-        if not 1 <= int(slot) <= 63:
-            raise ValueError("install_queries: slot must be in 1..63")
-        texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
-        ids, am = encode_queries(texts, self.model_name_or_path, allow_standin=self.allow_standin_tokenizer)
-        o2w = dict(object2weight or {})
-        for o in target_objects:
-            o2w.setdefault(o, 1.0)
-        for o in cue_objects:
-            o2w.setdefault(o, 0.5)
-        self.scorer.set_queries(ids, am, [float(o2w.get(t[0], 0.5)) for t in texts], slot=int(slot))
+        texts, (slot, ids, am, weights) = self._query_entry(slot, target_objects, cue_objects, object2weight)
+        self.scorer.set_queries(ids, am, weights, slot=slot)
         return texts
 
     def _query_entry(self, slot, target_objects, cue_objects, object2weight):
+        """(texts of the slot, (slot, token ids, attention mask, class weights)) of one question: blank query appended, targets
+        weigh 1.0 and cues 0.5 unless ``object2weight`` says otherwise (interface_searcher.py:88-91, 135-137)."""
         if not 1 <= int(slot) <= 63:
             raise ValueError("install_queries: slot must be in 1..63")
         texts = [[obj.strip()] for obj in list(target_objects) + list(cue_objects)] + [[' ']]
