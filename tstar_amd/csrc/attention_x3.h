@@ -19,6 +19,10 @@
 //    (80-B rows, keys permuted so that a lane's eight keys of a step are one 16-B chunk; V is transposed while staged) triple-buffered because tile t + 2 is
 //    written while tile t is read: 69 KB per workgroup, 2 workgroups per CU (256 registers per wave).
 //  * T = 32 n + 1 (577): the straggler key is folded in with f32 VALU ops after the loop (q rebuilt exactly from its terms).
+//  * measured (B = 256, T = 577, 12 heads; tools/lab/attn_lab.hip, profiles/r05_attention_x3_lab.log, r05_attention_x3_counters.md):
+//    154 TFLOP/s algorithmic (0.92 PFLOP/s executed) against 120-125 for attention_f32_kernel, 147 vs 103 inside the bench; error
+//    against float64 below the f32 kernel's (tests/test_gpu_kernels.py::test_attention_x3).  Matrix pipe busy 0.51: the kernel is
+//    bound by VALU issue, 7.5 VALU instructions per MFMA (the exact splits of P and of the staged K / V cost 5.5 per element).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
