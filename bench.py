@@ -56,7 +56,10 @@ def parse():
                     help="timed steps = searched videos per rank; default 16 (two lock-step groups of 8), 48 with --heuristic yolo (two groups of 24)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=16, help="grid side g (g*g frames per iteration)")
-    ap.add_argument("--max-batch", type=int, default=256, help="detector images per forward chunk")
+    ap.add_argument("--max-batch", type=int, default=512,
+                    help="detector images per forward chunk (workspace size; NOT the 256 frames per iteration of configs[1], which is the 16x16 grid): "
+                         "a lock-step group of 8 verifies ~360 frames per iteration, one chunk at 512 instead of 256 + ~104 "
+                         "(11.81 k vs 11.69 k frames/s same-box, profiles/r05_owl_maxbatch_sweep.log)")
     ap.add_argument("--yolo-max-batch", type=int, default=76,
                     help="YOLO-World backend: detector images per forward chunk.  Sized for the chip, not a power of two: the halo conv "
                          "kernel holds 3 workgroups per CU (768 slots) and a 40x40 / 256-channel layer is 20 B workgroups, an 80x80 / 128 "
