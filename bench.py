@@ -454,8 +454,8 @@ def other_configs():
     import subprocess
     runs = {
         "configs[3] yolo": ["--heuristic", "yolo", "--steps", "48"],
-        "configs[4] bf16 weights, 14400 frames, K=32, grid 15": ["--weights", "bf16", "--nframes", "14400", "--grid", "15", "--search-nframes", "32", "--steps", "8"],
-        "configs[1] on the native f32 MFMA tiles (the headline mode of rounds 1-4)": ["--weights", "f32", "--steps", "8"],
+        "configs[4] bf16 weights, 14400 frames, K=32, grid 15": ["--weights", "bf16", "--nframes", "14400", "--grid", "15", "--search-nframes", "32", "--steps", "16"],
+        "configs[1] on the native f32 MFMA tiles (the headline mode of rounds 1-4)": ["--weights", "f32", "--steps", "16"],
     }
     out = {}
     # the children are plain 1-GPU runs of their own: no launcher variables, none of this process's TSTAR_* overrides

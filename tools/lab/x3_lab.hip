@@ -582,6 +582,165 @@ __global__ __launch_bounds__(256, MINW) void gemm_w2_v2(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// two-term mode with BOTH operands through LDS (the library's two-term tile keeps W in LDS: 4 MFMAs per loaded KB are too few for the
+// global -> VGPR weight path) on the per-wave pipeline: A fragments double-buffered in registers (read a whole step ahead), W fragments
+// re-read right after their pair's last product (8 MFMAs ahead), staging of the next K tile (A split into two planes, W copied) in pieces
+// between the MFMA groups of the tile's first step, ONE barrier per K tile between its two steps, buffer loads, no branches in the loop.
+// W here is plain bf16 [N][K] row-major (the library's layout for this mode).
+template <int TM, int TN, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_w2l_v2(const float* __restrict__ A, const unsigned short* __restrict__ Wb,
+                                                         float* __restrict__ C, int M, int N, int K) {
+    static_assert(TN % 2 == 0, "column tiles go in pairs");
+    ClockProbe probe;
+    constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, BK = 32;
+    constexpr int A_T = BM * 64, W_T = BN * 64, BUF = 2 * A_T + W_T;
+    constexpr int NA = BM / 32, NB = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt = N / BN, mt = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int c4 = t & 7, r0 = t >> 3;            // A staging: rows r0 + 32 i, float4 column c4
+    const int wc = t & 3, wr = t >> 2;            // W staging: rows wr + 64 i, 16-B chunk wc
+    unsigned aoff[NA], woff[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { int ar = m0 + r0 + 32 * i; ar = ar < M ? ar : M - 1; aoff[i] = (unsigned)(ar - m0) * (unsigned)K * 4u + c4 * 16; }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) woff[i] = (unsigned)(wr + 64 * i) * (unsigned)K * 2u + wc * 16;
+    const int nk = K / BK;
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)m0 * K), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Wb + (size_t)n0 * K), 0, 0x7fffffff, 0x00020000);
+    const int sw = (l31 >> 2) & 3;
+    const int rdA0 = (wm * TM * 32 + l31) * 64 + ((h ^ sw) << 4), rdA1 = rdA0 ^ 32;
+    const int rdW0 = 2 * A_T + (wn * TN * 32 + l31) * 64 + ((h ^ sw) << 4), rdW1 = rdW0 ^ 32;
+    const int wrA = r0 * 64 + (((c4 >> 1) ^ ((r0 >> 2) & 3)) << 4) + (c4 & 1) * 8;
+    const int wrW = 2 * A_T + wr * 64 + ((wc ^ ((wr >> 2) & 3)) << 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[NA];
+    u32x4 rb[NB];
+    bf16x8 a0[2][TM], a1[2][TM], w[TN];
+    unsigned sp[2][2];
+
+    auto gloadAW = [&](int kt) __attribute__((always_inline)) {
+        kt = kt < nk ? kt : nk - 1;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, (int)aoff[i], kt * (BK * 4), 0));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw_rsrc, (int)woff[i], kt * (BK * 2), 0);
+    };
+    auto rd = [&](const char* base, int off, int imm) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(base + off + imm);
+    };
+    // staging pieces: 2 * NA split halves (the 8-byte stores follow the second half of a float4), then NB weight stores
+    constexpr int NPIECE = 2 * NA + NB;
+    auto stage_piece = [&](auto P, char* wbase) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value;
+        if constexpr (p < 2 * NA) {
+            constexpr int i = p >> 1, hf = p & 1;
+            split2_rn2(ra[i][2 * hf], ra[i][2 * hf + 1], sp[hf]);
+            if constexpr (hf == 1) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    u32x2 v; v[0] = sp[0][k]; v[1] = sp[1][k];
+                    *reinterpret_cast<u32x2*>(wbase + wrA + k * A_T + i * 2048) = v;
+                }
+            }
+        } else {
+            constexpr int i = p - 2 * NA;
+            *reinterpret_cast<u32x4*>(wbase + wrW + i * 4096) = rb[i];
+        }
+    };
+    auto mf = [&](const bf16x8& a, const bf16x8& b, f32x16& c) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    };
+    // one K = 16 step; S = step inside the tile = set of the A fragments in use; rbase / (roffA, roffW): where the NEXT step's fragments are
+    auto step = [&](auto SS, const char* rbase, int roffA, int roffW, char* wbase, int ktload) __attribute__((always_inline)) {
+        constexpr int S = decltype(SS)::value;
+        constexpr int GP = TN / 2, NG = 2 * GP, PPG = (NPIECE + 1 + NG - 1) / NG;
+        auto after_group = [&](auto G) __attribute__((always_inline)) {
+            constexpr int gi = decltype(G)::value;
+            if constexpr (S == 0) {
+                [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
+                    ([&] {
+                        constexpr int p = gi * PPG + Q;
+                        if constexpr (p < NPIECE) stage_piece(std::integral_constant<int, p>{}, wbase);
+                        if constexpr (p == NPIECE) gloadAW(ktload);
+                    }(), ...);
+                }(std::make_integer_sequence<int, PPG>{});
+            }
+            if constexpr (gi == 0) {                 // the next step's A fragments, a whole step ahead
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { a1[S ^ 1][i] = rd(rbase, roffA, A_T + i * 2048); a0[S ^ 1][i] = rd(rbase, roffA, i * 2048); }
+            }
+            FENCE();
+        };
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = 2 * JP;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a1[S][i], w[j0 + jj], acc[i][j0 + jj]);
+                after_group(std::integral_constant<int, 2 * JP + 0>{});
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[j0 + jj], acc[i][j0 + jj]);
+                w[j0] = rd(rbase, roffW, j0 * 2048);                      // this pair's fragments of the next step
+                w[j0 + 1] = rd(rbase, roffW, (j0 + 1) * 2048);
+                after_group(std::integral_constant<int, 2 * JP + 1>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+    };
+
+    gloadAW(0);
+    [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
+        (stage_piece(std::integral_constant<int, P>{}, smem), ...);
+    }(std::make_integer_sequence<int, NPIECE>{});
+    gloadAW(1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { a0[0][i] = rd(smem, rdA0, i * 2048); a1[0][i] = rd(smem, rdA0, A_T + i * 2048); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) w[j] = rd(smem, rdW0, j * 2048);
+    __builtin_amdgcn_s_setprio(1);
+    FENCE();
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * BUF;
+        char* nxt = smem + ((kt + 1) & 1) * BUF;
+        step(std::integral_constant<int, 0>{}, cur, rdA1, rdW1, nxt, kt + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        FENCE();
+        step(std::integral_constant<int, 1>{}, nxt, rdA0, rdW0, nxt, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    }
+    probe.done();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 static unsigned short f2bf_rn(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
 static float bf2f(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
 
@@ -740,6 +899,60 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < hC.size(); ++i) { const double e = hC[i] - ref[i]; maxe = fmax(maxe, fabs(e)); se += e * e; }
             printf("  K=%4d two-term v2 128x256                      max|err| %.3e  rms err %.3e%s\n", k, maxe, sqrt(se / hC.size()), (maxe < 1e-3 && maxe == maxe) ? "" : "   <-- WRONG");
             CK(hipFree(a2));
+        }
+        auto run_w2l = [&](auto kern, int BM, int BN, const float* a, const unsigned short* wb, float* c, int m, int n, int k, int iters) {
+            const int lds = 2 * (2 * BM + BN) * 64;
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            const int nwg = ((m + BM - 1) / BM) * (n / BN);
+            if (iters == 0) { hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, 0, a, wb, c, m, n, k); CK(hipDeviceSynchronize()); return 0.f; }
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, 0, a, wb, c, m, n, k);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, 0, a, wb, c, m, n, k);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            return ms / iters;
+        };
+        unsigned short* Wb16; CK(hipMalloc(&Wb16, (size_t)NMAX * KMAX * 2));
+        if (!only) for (int k : {64, 768, 3072}) {
+            const int m = 300, n = 256;
+            std::vector<float> a((size_t)m * k);
+            std::vector<unsigned short> wb((size_t)n * k);
+            for (auto& v : a) v = gauss();
+            for (auto& v : wb) v = f2bf_rn(gauss() * 0.03f);
+            std::vector<double> ref((size_t)m * n);
+            for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) {
+                double r = 0;
+                for (int kk = 0; kk < k; ++kk) r += (double)a[(size_t)i * k + kk] * (double)bf2f(wb[(size_t)j * k + kk]);
+                ref[(size_t)i * n + j] = r;
+            }
+            float* a2; CK(hipMalloc(&a2, a.size() * 4)); CK(hipMemcpy(a2, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(Wb16, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+            std::vector<float> hC((size_t)m * n);
+            CK(hipMemset(C, 0xFF, hC.size() * 4));
+            run_w2l(gemm_w2l_v2<2, 4, 2>, 128, 256, a2, Wb16, C, m, n, k, 0);
+            CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+            double maxe = 0, se = 0;
+            for (size_t i = 0; i < hC.size(); ++i) { const double e = hC[i] - ref[i]; maxe = fmax(maxe, fabs(e)); se += e * e; }
+            printf("  K=%4d two-term v2, W through LDS, 128x256       max|err| %.3e  rms err %.3e%s\n", k, maxe, sqrt(se / hC.size()), (maxe < 1e-3 && maxe == maxe) ? "" : "   <-- WRONG");
+            CK(hipFree(a2));
+        }
+        {
+            std::vector<unsigned short> wb((size_t)NMAX * KMAX);
+            for (size_t i = 0; i < wb.size(); ++i) wb[i] = f2bf_rn(hW[i]);
+            CK(hipMemcpy(Wb16, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+        }
+        for (auto sh : shapes) {
+            const double fl = 2.0 * M * sh.N * sh.K;
+            for (int rep = 0; rep < 2; ++rep) {
+                unsigned long long z[2] = {0, 0}, c[2];
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof(z)));
+                const float ms = run_w2l(gemm_w2l_v2<2, 4, 2>, 128, 256, A, Wb16, C, M, sh.N, sh.K, 5);
+                CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_clk), sizeof(c)));
+                const double ghz = c[1] ? (double)c[0] / (double)c[1] * 0.1 : 0.0;
+                printf("N=%4d K=%4d two-term v2, W through LDS, 128x256                    %7.3f ms  %6.1f TFLOP/s algorithmic  %6.0f executed  %.2f GHz\n", sh.N, sh.K, ms,
+                       fl / ms / 1e9, 2 * fl / ms / 1e9, ghz);
+            }
         }
         for (auto sh : shapes) {
             const double fl = 2.0 * M * sh.N * sh.K;
