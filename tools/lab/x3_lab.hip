@@ -414,6 +414,226 @@ __global__ __launch_bounds__(256, MINW) void gemm_x3_v2(const float* __restrict_
     probe.done();
 }
 
+// the same loop with WM waves along M (WM = 4: a 256 x 256 block tile of 8 waves, one block per CU: the four waves of a column pair load the SAME weight
+// fragments -- L1 hits instead of L2 requests -- and the activation tile is staged once for twice the MFMAs)
+template <int TM, int TN, int WM, int MINW, int STAGE, int PRIO>
+__global__ __launch_bounds__(128 * WM, MINW) void gemm_x3_v2w(const float* __restrict__ A, const char* __restrict__ Wp,
+                                                        float* __restrict__ C, int M, int N, int K) {
+    static_assert(TN % 2 == 0, "column tiles go in pairs");
+    ClockProbe probe;
+    constexpr int NTHR = 128 * WM, RPP = NTHR / 8, BM = WM * TM * 32, BN = 2 * TN * 32, BK = 32;
+    constexpr int A_T = BM * 64, BUF = 3 * A_T;
+    constexpr int NA = BM / RPP;                // float4 loads per thread per K tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt = N / BN, mt = (M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, mt * nt);
+    const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int c4 = t & 7, r0 = t >> 3;
+    // activation rows: ONE uniform base per K tile (SGPRs) + a 32-bit byte offset per staged row (clamped to the last row)
+    unsigned aoff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { int ar = m0 + r0 + RPP * i; ar = ar < M ? ar : M - 1; aoff[i] = (unsigned)(ar - m0) * (unsigned)K * 4u + c4 * 16; }
+    const char* abase = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+    const int nsteps = K / 16, nk = K / BK;
+    // fragment stream of this wave's column tile j: (uniform base) + step * 3072 + ph * 1024 + lane * 16, ph = 2 - kw
+    const char* wrow = Wp + (size_t)((n0 >> 5) + wn * TN) * nsteps * 3072;
+    const unsigned voff = lane * 16;
+    // LDS: fragment read offsets of step 0 / 1 (row swizzle term (l31 >> 2) & 3), staging write offset
+    const int rd0 = (wm * TM * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
+    const int rd1 = rd0 ^ 32;
+    const int wr0 = r0 * 64 + (((c4 >> 1) ^ ((r0 >> 2) & 3)) << 4) + (c4 & 1) * 8;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NA];
+    u32x4 w[3][TN];                 // w[kw][j]: plane kw of column tile j, current step
+    bf16x8 a0[2][TM], a1[TM], a2[TM];
+
+    // buffer loads: a resource descriptor per operand (SGPRs), a 32-bit lane offset (VGPR), a uniform 32-bit offset (SGPR, SALU
+    // arithmetic) and an immediate -- no 64-bit VALU address arithmetic, no 64-bit pointer registers
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wrow), 0, 0x7fffffff, 0x00020000);
+    auto gloadA = [&](int kt) __attribute__((always_inline)) {
+        kt = kt < nk ? kt : nk - 1;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, (int)aoff[i], kt * (BK * 4), 0));
+    };
+    auto wload = [&](auto KW, auto J, int g) __attribute__((always_inline)) {
+        constexpr int kw = decltype(KW)::value, j = decltype(J)::value;
+        g = g < nsteps ? g : nsteps - 1;
+        w[kw][j] = __builtin_amdgcn_raw_buffer_load_b128(rw_rsrc, (int)voff + (2 - kw) * 1024, (j * nsteps + g) * 3072, 0);
+    };
+    auto rdA = [&](const char* base, int off, int plane, int i) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(base + off + plane * A_T + i * 2048);
+    };
+    // staging piece p of NA * 2: half p & 1 of float4 p >> 1; the three 8-byte stores follow the second half
+    unsigned sp[2][3];
+    auto stage_piece = [&](auto P, char* wbase) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value, i = p >> 1, hf = p & 1;
+        split2_rn3(ra[i][2 * hf], ra[i][2 * hf + 1], sp[hf]);
+        if constexpr (hf == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                u32x2 v; v[0] = sp[0][k]; v[1] = sp[1][k];
+                *reinterpret_cast<u32x2*>(wbase + wr0 + k * A_T + i * (RPP * 64)) = v;
+            }
+        }
+    };
+    auto mf = [&](const bf16x8& a, const u32x4& b, f32x16& c) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+
+    // one K = 16 step.  S = step inside the tile (selects the a0 set); rbase / roff: where the NEXT step's fragments are read;
+    // wbase: where the next tile's planes are written (only S == 0 stages); gnext: fragment-stream step of the reloads
+    auto step = [&](auto SS, const char* rbase, int roff, char* wbase, int gnext, int ktload) __attribute__((always_inline)) {
+        constexpr int S = decltype(SS)::value;
+        constexpr int NPIECE = NA * 2;
+        int grp = 0;                        // MFMA groups issued so far in this step (compile-time after unrolling)
+        auto after_group = [&](auto G) __attribute__((always_inline)) {
+            constexpr int g = decltype(G)::value;
+            if constexpr (S == 0 && STAGE == 0) {
+                // NPIECE split pieces + the load of the tile after next, PPG of them per MFMA group
+                constexpr int NG = 6 * (TN / 2), PPG = (NPIECE + 1 + NG - 1) / NG;
+                [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
+                    ([&] {
+                        constexpr int p = g * PPG + Q;
+                        if constexpr (p < NPIECE) stage_piece(std::integral_constant<int, p>{}, wbase);
+                        if constexpr (p == NPIECE) gloadA(ktload);
+                    }(), ...);
+                }(std::make_integer_sequence<int, PPG>{});
+            }
+            if constexpr (g == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[S ^ 1][i] = rdA(rbase, roff, 0, i);
+            }
+            FENCE();
+        };
+        (void)grp;
+        constexpr int GP = TN / 2;          // column-tile pairs
+        // w0 fragments: a2, a1, a0
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = 2 * JP;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a2[i], w[0][j0 + jj], acc[i][j0 + jj]);
+                after_group(std::integral_constant<int, 3 * JP + 0>{});
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a1[i], w[0][j0 + jj], acc[i][j0 + jj]);
+                after_group(std::integral_constant<int, 3 * JP + 1>{});
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[0][j0 + jj], acc[i][j0 + jj]);
+                wload(std::integral_constant<int, 0>{}, std::integral_constant<int, j0>{}, gnext);
+                wload(std::integral_constant<int, 0>{}, std::integral_constant<int, j0 + 1>{}, gnext);
+                after_group(std::integral_constant<int, 3 * JP + 2>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+        // a2's last product has issued: next step's a2
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a2[i] = rdA(rbase, roff, 2, i);
+        FENCE();
+        // w1 fragments: a1, a0
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = 2 * JP;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a1[i], w[1][j0 + jj], acc[i][j0 + jj]);
+                after_group(std::integral_constant<int, 3 * GP + 2 * JP + 0>{});
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[1][j0 + jj], acc[i][j0 + jj]);
+                wload(std::integral_constant<int, 1>{}, std::integral_constant<int, j0>{}, gnext);
+                wload(std::integral_constant<int, 1>{}, std::integral_constant<int, j0 + 1>{}, gnext);
+                after_group(std::integral_constant<int, 3 * GP + 2 * JP + 1>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = rdA(rbase, roff, 1, i);
+        FENCE();
+        // w2 fragments: a0
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = 2 * JP;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[2][j0 + jj], acc[i][j0 + jj]);
+                wload(std::integral_constant<int, 2>{}, std::integral_constant<int, j0>{}, gnext);
+                wload(std::integral_constant<int, 2>{}, std::integral_constant<int, j0 + 1>{}, gnext);
+                after_group(std::integral_constant<int, 5 * GP + JP>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+        if constexpr (S == 0 && STAGE == 1) {
+            [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
+                (stage_piece(std::integral_constant<int, P>{}, wbase), ...);
+            }(std::make_integer_sequence<int, NPIECE>{});
+            gloadA(ktload);
+            FENCE();
+        }
+    };
+
+    // ---- prologue: tile 0 into LDS buffer 0, step 0's weight fragments, tile 1 into the staging registers
+    gloadA(0);
+    [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
+        ((wload(std::integral_constant<int, 0>{}, std::integral_constant<int, J>{}, 0),
+          wload(std::integral_constant<int, 1>{}, std::integral_constant<int, J>{}, 0),
+          wload(std::integral_constant<int, 2>{}, std::integral_constant<int, J>{}, 0)), ...);
+    }(std::make_integer_sequence<int, TN>{});
+    [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
+        (stage_piece(std::integral_constant<int, P>{}, smem), ...);
+    }(std::make_integer_sequence<int, NA * 2>{});
+    gloadA(1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { a0[0][i] = rdA(smem, rd0, 0, i); a1[i] = rdA(smem, rd0, 1, i); a2[i] = rdA(smem, rd0, 2, i); }
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+    FENCE();
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * BUF;
+        char* nxt = smem + ((kt + 1) & 1) * BUF;
+        // step 0: next fragments = this tile's step 1; stages tile kt + 1 into nxt; after the staging registers are free, loads tile kt + 2
+        step(std::integral_constant<int, 0>{}, cur, rd1, nxt, 2 * kt + 1, kt + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        FENCE();
+        // step 1: next fragments = tile kt + 1, step 0
+        step(std::integral_constant<int, 1>{}, nxt, rd0, nxt, 2 * kt + 2, 0);
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) C[(size_t)row * N + col] = acc[i][j][r];
+            }
+        }
+    }
+    probe.done();
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // two-term mode (bf16 weights = ONE exact plane, activations as two round-to-nearest bf16 terms: BASELINE configs[4]) on the same
 // per-wave pipeline: weight fragments global -> VGPR in TWO slot sets (a fragment is re-loaded two steps ahead right after its last
@@ -761,15 +981,15 @@ static void pack_w(const float* W, int N, int K, std::vector<unsigned short>& ou
 }
 
 template <class KERN>
-static float run(KERN k, int BM, int BN, const float* A, const char* Wp, float* C, int M, int N, int K, int iters) {
+static float run(KERN k, int BM, int BN, const float* A, const char* Wp, float* C, int M, int N, int K, int iters, int nthr = 256) {
     const int lds = 2 * 3 * BM * 64;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int nwg = ((M + BM - 1) / BM) * (N / BN);
-    if (iters == 0) { hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K); CK(hipDeviceSynchronize()); return 0.f; }
+    if (iters == 0) { hipLaunchKernelGGL(k, dim3(nwg), dim3(nthr), lds, 0, A, Wp, C, M, N, K); CK(hipDeviceSynchronize()); return 0.f; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(nthr), lds, 0, A, Wp, C, M, N, K);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, 0, A, Wp, C, M, N, K);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(nwg), dim3(nthr), lds, 0, A, Wp, C, M, N, K);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / iters;
@@ -800,6 +1020,7 @@ int main(int argc, char** argv) {
         {"base 128x128", 128, 128, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_base<2, 2, 2>, 128, 128, a, w, c, m, n, k, it); }},
         {"v2   128x128 interleaved", 128, 128, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_v2<2, 2, 2, 0, 0>, 128, 128, a, w, c, m, n, k, it); }},
         {"v2   128x128 interleaved 3 blocks/CU", 128, 128, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_v2<2, 2, 3, 0, 0>, 128, 128, a, w, c, m, n, k, it); }},
+        {"v2w  256x256 8 waves interleaved", 256, 256, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_v2w<2, 4, 4, 2, 0, 1>, 256, 256, a, w, c, m, n, k, it, 512); }},
         {"base 64x128", 64, 128, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_base<1, 2, 2>, 64, 128, a, w, c, m, n, k, it); }},
         {"v2   64x128 interleaved", 64, 128, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_v2<1, 2, 2, 0, 0>, 64, 128, a, w, c, m, n, k, it); }},
     };
