@@ -533,6 +533,8 @@ def test_native_curfit_bit_identical_to_scipy(golden_dir):
     from scipy.interpolate import UnivariateSpline
     from tstar_amd import spline_worker as SW
     assert SW.curfit(np.arange(8.0), np.arange(8.0) ** 2 % 3, 0.5) is not None, "libtstar_fitpack.so missing: run python -m tstar_amd.build"
+    lib = SW._native_fit()
+    lib.tstar_curfit_pairing.restype = None
 
     def check(x, y, s, tag):
         with warnings.catch_warnings():
@@ -543,12 +545,14 @@ def test_native_curfit_bit_identical_to_scipy(golden_dir):
                 assert SW.curfit(x, y, s) is None, tag          # FITPACK warning: the native path steps aside, scipy raises it
                 return 0
         t, c, k = sp._eval_args
-        for lanes in (1, 4, 8):
+        for lanes, paired in ((1, 1), (4, 1), (8, 1), (4, 0), (8, 0)):     # paired: two batches per steady loop (round 5), same bits
+            lib.tstar_curfit_pairing(paired)
             got = SW.curfit(x, y, s, lanes)
+            lib.tstar_curfit_pairing(1)
             assert got is not None, (tag, lanes)
             tt, cc, kk, fp, ier = got
-            assert kk == 3 and len(tt) == len(t) and np.array_equal(tt, t), (tag, lanes, len(tt), len(t))
-            assert np.array_equal(cc[:len(t) - 4], c[:len(t) - 4]) and fp == sp.get_residual(), (tag, lanes)
+            assert kk == 3 and len(tt) == len(t) and np.array_equal(tt, t), (tag, lanes, paired, len(tt), len(t))
+            assert np.array_equal(cc[:len(t) - 4], c[:len(t) - 4]) and fp == sp.get_residual(), (tag, lanes, paired)
         return len(t)
 
     probs = _reference_default_fit_problems()

@@ -26,6 +26,9 @@
 // of a batch the column data move through the lanes like a shift register (one scalar load and one scalar store per array and
 // step); a Givens rotation costs three divisions and one square root (operands selected BEFORE the division, which is what
 // the library's two branches compute).  The widest form the CPU supports is picked at run time; all forms give the same bits.
+// Round 5: two consecutive batches run their steady states in ONE loop (rotate_pair: the second batch 2 W columns behind the first),
+// i.e. two independent division / root chains in flight per iteration: the 63 fits of a reference-default search 179 -> 146 ms on the
+// GPU box's EPYC 9575F (AVX-512), 392 -> 324 ms on the build container's Xeon; same bits (tests run both forms).
 //
 // Not on the GPU: the fit is a few hundred KB of sequential, latency-bound float64 work per search iteration.
 #if defined(__x86_64__)
@@ -35,6 +38,7 @@
 #define TSTAR_FITPACK_SIMD 0          // other hosts: the sequential form only (same bits)
 #endif
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -181,6 +185,9 @@ inline double fprati(double& p1, double& f1, double p2, double f2, double& p3, d
 // ---- the O(n^2) step: rows 1..n8 of b (weighted by 1/p) rotated into the band matrix g (5 columns) and the right-hand side c.
 // g column i (1-based) lives at g + (i - 1) * gs + PAD, row j (1-based) at [.. + j]; PAD elements of slack on both sides.
 constexpr int PAD = 16;
+static bool env_off(const char* k) { const char* v = std::getenv(k); return v && v[0] == '0'; }
+// two batches per steady loop; TSTAR_FITPACK_PAIR=0 or tstar_curfit_pairing(0) turn it off (tests / timing: same bits either way)
+static bool g_pair_batches = !env_off("TSTAR_FITPACK_PAIR");
 
 // sequential form (the library's loop), used for the rows a full batch does not cover and as the reference of the skewed form
 inline void rotate_rows_seq(const double* b, double pinv, double* g, int gs, double* c, int it0, int it1, int nk1, int n8) {
@@ -306,6 +313,54 @@ inline void rotate_rows_skewed(RowState<W>& st, double* g, int gs, double* c, in
     STOREU(g1 + base, G1); STOREU(g2 + base, G2); STOREU(g3 + base, G3); STOREU(g4 + base, G4); STOREU(g5 + base, G5); STOREU(c + base, CC); \
     STOREU(st.h1, H1); STOREU(st.h2, H2); STOREU(st.h3, H3); STOREU(st.h4, H4); STOREU(st.h5, H5); STOREU(st.yi, YI);
 
+// Two batches in one loop (round 5): batch A = rows it0 .. it0 + W - 1 at time T, batch B = the next W rows at time T - 2 W, i.e. B's
+// columns are A's shifted down by W (baseB = baseA - W): the column that leaves A at lane 0 in a step is the one B takes in at its top
+// lane at the end of the same step, so B never touches a column A has not finished -- the sequential order per (row, column) is kept
+// and so are the bits.  A step of one batch is ONE dependent chain (division -> root -> two divisions -> the next pivot: ~60-90
+// cycles of latency per column); two independent chains per loop iteration let the out-of-order core overlap them.
+#define TSTAR_STEADY_STEP(S, VT, SET1, MUL, ADD, SUB, DIV, SQRT, ABS, SELECT_GE, LANE0, SHIFT_IN, ZERO)                                     \
+    {                                                                                                                                       \
+        const VT piv = H1##S, ww = G1##S;                                                                                                   \
+        const VT sa = ABS(piv);                                                                                                             \
+        const VT rr = DIV(SELECT_GE(sa, ww, ww, piv), SELECT_GE(sa, ww, piv, ww));                                                          \
+        const VT dd = MUL(SELECT_GE(sa, ww, sa, ww), SQRT(ADD(one, MUL(rr, rr))));                                                          \
+        const VT cs = DIV(ww, dd), sn = DIV(piv, dd);                                                                                       \
+        G1##S = dd;                                                                                                                         \
+        const VT nc = ADD(MUL(cs, CC##S), MUL(sn, YI##S));                                                                                  \
+        YI##S = SUB(MUL(cs, YI##S), MUL(sn, CC##S));                                                                                        \
+        CC##S = nc;                                                                                                                         \
+        const VT n2 = ADD(MUL(cs, G2##S), MUL(sn, H2##S)); H1##S = SUB(MUL(cs, H2##S), MUL(sn, G2##S)); G2##S = n2;                         \
+        const VT n3 = ADD(MUL(cs, G3##S), MUL(sn, H3##S)); H2##S = SUB(MUL(cs, H3##S), MUL(sn, G3##S)); G3##S = n3;                         \
+        const VT n4 = ADD(MUL(cs, G4##S), MUL(sn, H4##S)); H3##S = SUB(MUL(cs, H4##S), MUL(sn, G4##S)); G4##S = n4;                         \
+        const VT n5 = ADD(MUL(cs, G5##S), MUL(sn, H5##S)); H4##S = SUB(MUL(cs, H5##S), MUL(sn, G5##S)); G5##S = n5;                         \
+        H5##S = ZERO();                                                                                                                     \
+        g1[base##S] = LANE0(G1##S); g2[base##S] = LANE0(G2##S); g3[base##S] = LANE0(G3##S); g4[base##S] = LANE0(G4##S);                     \
+        g5[base##S] = LANE0(G5##S); c[base##S] = LANE0(CC##S);                                                                              \
+        G1##S = SHIFT_IN(G1##S, g1[base##S + W]); G2##S = SHIFT_IN(G2##S, g2[base##S + W]); G3##S = SHIFT_IN(G3##S, g3[base##S + W]);       \
+        G4##S = SHIFT_IN(G4##S, g4[base##S + W]); G5##S = SHIFT_IN(G5##S, g5[base##S + W]); CC##S = SHIFT_IN(CC##S, c[base##S + W]);        \
+    }
+#define TSTAR_STEADY2_BODY(VT, LOADU, STOREU, SET1, MUL, ADD, SUB, DIV, SQRT, ABS, SELECT_GE, LANE0, SHIFT_IN, ZERO)                        \
+    VT H1A = LOADU(sa_.h1), H2A = LOADU(sa_.h2), H3A = LOADU(sa_.h3), H4A = LOADU(sa_.h4), H5A = LOADU(sa_.h5), YIA = LOADU(sa_.yi);         \
+    VT H1B = LOADU(sb_.h1), H2B = LOADU(sb_.h2), H3B = LOADU(sb_.h3), H4B = LOADU(sb_.h4), H5B = LOADU(sb_.h5), YIB = LOADU(sb_.yi);         \
+    int baseA = it0 + T0 - W + 1, baseB = baseA - W;                                                                                        \
+    /* B's register-resident columns first: they end where A's begin (B's entering column baseB + W - 1 is A's baseA - 1, final) */        \
+    VT G1B = LOADU(g1 + baseB), G2B = LOADU(g2 + baseB), G3B = LOADU(g3 + baseB), G4B = LOADU(g4 + baseB), G5B = LOADU(g5 + baseB),         \
+       CCB = LOADU(c + baseB);                                                                                                              \
+    VT G1A = LOADU(g1 + baseA), G2A = LOADU(g2 + baseA), G3A = LOADU(g3 + baseA), G4A = LOADU(g4 + baseA), G5A = LOADU(g5 + baseA),         \
+       CCA = LOADU(c + baseA);                                                                                                              \
+    const VT one = SET1(1.0);                                                                                                               \
+    for (int T = T0; T <= T1; ++T, ++baseA, ++baseB) {                                                                                      \
+        TSTAR_STEADY_STEP(A, VT, SET1, MUL, ADD, SUB, DIV, SQRT, ABS, SELECT_GE, LANE0, SHIFT_IN, ZERO)                                     \
+        TSTAR_STEADY_STEP(B, VT, SET1, MUL, ADD, SUB, DIV, SQRT, ABS, SELECT_GE, LANE0, SHIFT_IN, ZERO)                                     \
+    }                                                                                                                                       \
+    /* A's columns back first, then B's (B's top lane holds column baseB + W - 1 = baseA - 1 as loaded: the same value A stored) */         \
+    STOREU(g1 + baseA, G1A); STOREU(g2 + baseA, G2A); STOREU(g3 + baseA, G3A); STOREU(g4 + baseA, G4A); STOREU(g5 + baseA, G5A);            \
+    STOREU(c + baseA, CCA);                                                                                                                 \
+    STOREU(g1 + baseB, G1B); STOREU(g2 + baseB, G2B); STOREU(g3 + baseB, G3B); STOREU(g4 + baseB, G4B); STOREU(g5 + baseB, G5B);            \
+    STOREU(c + baseB, CCB);                                                                                                                 \
+    STOREU(sa_.h1, H1A); STOREU(sa_.h2, H2A); STOREU(sa_.h3, H3A); STOREU(sa_.h4, H4A); STOREU(sa_.h5, H5A); STOREU(sa_.yi, YIA);           \
+    STOREU(sb_.h1, H1B); STOREU(sb_.h2, H2B); STOREU(sb_.h3, H3B); STOREU(sb_.h4, H4B); STOREU(sb_.h5, H5B); STOREU(sb_.yi, YIB);
+
 #if TSTAR_FITPACK_SIMD
 __attribute__((target("avx512f,avx512dq"))) inline void steady8(RowState<8>& st, double* g, int gs, double* c, int it0, int T0, int T1) {
     constexpr int W = 8;
@@ -315,6 +370,13 @@ __attribute__((target("avx512f,avx512dq"))) inline void steady8(RowState<8>& st,
 #define LANE512(v) _mm_cvtsd_f64(_mm512_castpd512_pd128(v))
     TSTAR_STEADY_BODY(__m512d, _mm512_loadu_pd, _mm512_storeu_pd, _mm512_set1_pd, _mm512_mul_pd, _mm512_add_pd, _mm512_sub_pd, _mm512_div_pd,
                       _mm512_sqrt_pd, _mm512_abs_pd, SEL512, LANE512, SHIFT512, _mm512_setzero_pd)
+}
+// batch A (rows it0 ..) at times T0 .. T1 together with batch B (rows it0 + 8 ..) at times T0 - 16 .. T1 - 16
+__attribute__((target("avx512f,avx512dq"))) inline void steady8x2(RowState<8>& sa_, RowState<8>& sb_, double* g, int gs, double* c, int it0, int T0, int T1) {
+    constexpr int W = 8;
+    double* g1 = g + PAD; double* g2 = g + gs + PAD; double* g3 = g + 2 * gs + PAD; double* g4 = g + 3 * gs + PAD; double* g5 = g + 4 * gs + PAD;
+    TSTAR_STEADY2_BODY(__m512d, _mm512_loadu_pd, _mm512_storeu_pd, _mm512_set1_pd, _mm512_mul_pd, _mm512_add_pd, _mm512_sub_pd, _mm512_div_pd,
+                       _mm512_sqrt_pd, _mm512_abs_pd, SEL512, LANE512, SHIFT512, _mm512_setzero_pd)
 }
 
 __attribute__((target("avx2"))) inline void steady4(RowState<4>& st, double* g, int gs, double* c, int it0, int T0, int T1) {
@@ -326,6 +388,12 @@ __attribute__((target("avx2"))) inline void steady4(RowState<4>& st, double* g, 
 #define LANE256(v) _mm_cvtsd_f64(_mm256_castpd256_pd128(v))
     TSTAR_STEADY_BODY(__m256d, _mm256_loadu_pd, _mm256_storeu_pd, _mm256_set1_pd, _mm256_mul_pd, _mm256_add_pd, _mm256_sub_pd, _mm256_div_pd,
                       _mm256_sqrt_pd, ABS256, SEL256, LANE256, SHIFT256, _mm256_setzero_pd)
+}
+__attribute__((target("avx2"))) inline void steady4x2(RowState<4>& sa_, RowState<4>& sb_, double* g, int gs, double* c, int it0, int T0, int T1) {
+    constexpr int W = 4;
+    double* g1 = g + PAD; double* g2 = g + gs + PAD; double* g3 = g + 2 * gs + PAD; double* g4 = g + 3 * gs + PAD; double* g5 = g + 4 * gs + PAD;
+    TSTAR_STEADY2_BODY(__m256d, _mm256_loadu_pd, _mm256_storeu_pd, _mm256_set1_pd, _mm256_mul_pd, _mm256_add_pd, _mm256_sub_pd, _mm256_div_pd,
+                       _mm256_sqrt_pd, ABS256, SEL256, LANE256, SHIFT256, _mm256_setzero_pd)
 }
 
 #endif
@@ -353,10 +421,51 @@ inline void rotate_batch(const double* b, double pinv, double* g, int gs, double
     }
 }
 
+// Two consecutive batches (rows it0 .. it0 + 2 W - 1) with their steady states run as one loop: A fills and runs 2 W steps ahead,
+// B fills behind it, both run together while A is in its steady state, A drains, B finishes alone.  Any interleaving in which B
+// never touches a column A has not left is the sequential order per (row, column); each piece below is one of the single-batch forms.
+template <int W>
+inline void rotate_pair(const double* b, double pinv, double* g, int gs, double* c, int it0, int nk1, int n8) {
+    RowState<W> sa, sb;
+    auto init = [&](RowState<W>& st, int i0) {
+        for (int l = 0; l < W; ++l) {
+            const int it = i0 + W - 1 - l;
+            st.h1[l] = b[it * 5 + 0] * pinv; st.h2[l] = b[it * 5 + 1] * pinv; st.h3[l] = b[it * 5 + 2] * pinv;
+            st.h4[l] = b[it * 5 + 3] * pinv; st.h5[l] = b[it * 5 + 4] * pinv;
+            st.yi[l] = 0.0;
+        }
+    };
+    init(sa, it0); init(sb, it0 + W);
+    const int itb = it0 + W;
+    const int s0 = 2 * (W - 1), s1a = n8 - it0, s1b = n8 - itb;            // steady ranges [s0, s1] of the two batches (own time)
+    const int tea = nk1 - it0 + W - 1, teb = nk1 - itb + W - 1;            // their last time steps
+    const int lag = 2 * W, j0 = s0 + lag;                                    // joint range of A's time: [j0, s1a]; B's = A's - lag
+#if TSTAR_FITPACK_SIMD
+    auto steady1 = [&](RowState<W>& st, int i0, int T0, int T1) {
+        if (T1 < T0) return;
+        if constexpr (W == 8) steady8(st, g, gs, c, i0, T0, T1); else steady4(st, g, gs, c, i0, T0, T1);
+    };
+    rotate_rows_skewed<W>(sa, g, gs, c, it0, nk1, n8, 0, s0 - 1);           // A fills
+    steady1(sa, it0, s0, j0 - 1);                                            // A gets 2 W columns ahead
+    rotate_rows_skewed<W>(sb, g, gs, c, itb, nk1, n8, 0, s0 - 1);           // B fills (columns <= itb + s0 - 1 < A's lowest)
+    if constexpr (W == 8) steady8x2(sa, sb, g, gs, c, it0, j0, s1a); else steady4x2(sa, sb, g, gs, c, it0, j0, s1a);
+    rotate_rows_skewed<W>(sa, g, gs, c, it0, nk1, n8, s1a + 1, tea);        // A drains
+    steady1(sb, itb, s1a - lag + 1, s1b);                                    // B's remaining steady steps
+    rotate_rows_skewed<W>(sb, g, gs, c, itb, nk1, n8, s1b + 1, teb);        // B drains
+#else
+    (void)s0; (void)s1a; (void)s1b; (void)tea; (void)teb; (void)lag; (void)j0; (void)sa; (void)sb; (void)g; (void)gs; (void)c; (void)nk1;
+#endif
+}
+
 template <int W>
 inline void rotate_all(const double* b, double pinv, double* g, int gs, double* c, int nk1, int n8) {
     int it = 1;
     if constexpr (W > 1) {
+#if TSTAR_FITPACK_SIMD
+        // pairs while the joint steady range is long enough to pay for B's separate start (>= 4 W joint steps)
+        if (g_pair_batches)
+            for (; it + 2 * W - 1 <= n8 && (n8 - it) - (2 * (W - 1) + 2 * W) >= 4 * W; it += 2 * W) rotate_pair<W>(b, pinv, g, gs, c, it, nk1, n8);
+#endif
         // a batch pays ~2 W steps of pipeline fill: worth it while the rows are much longer than that
         for (; it + W - 1 <= n8 && nk1 - it > 6 * W; it += W) rotate_batch<W>(b, pinv, g, gs, c, it, nk1, n8);
     }
@@ -625,6 +734,10 @@ int tstar_curfit(const double* x, const double* y, int m, double s, int lanes, d
     (void)lanes;
     return curfit_scalar(x, y, m, s, t, c, n, fp, p_iterations);
 }
+
+// 1 (default): consecutive batches of the rotation pipeline run their steady states as one loop (two dependent chains in flight);
+// 0: one batch at a time (round 4's form).  Same bits either way; process-wide, for tests and timing.
+void tstar_curfit_pairing(int on) { g_pair_batches = on != 0; }
 
 int tstar_curfit_lanes(void) {
 #if TSTAR_FITPACK_SIMD
