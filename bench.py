@@ -612,6 +612,12 @@ def main():
         # groups of at most L items, balanced (5 items at L = 4 -> 3 + 2, not 4 + 1); PL consecutive groups alternate on the
         # GPU (tstar_amd.lockstep)
         ng = (len(items) + L - 1) // L
+        if PL > 1 and ng % PL and len(items) > 1:
+            # a group count that is not a multiple of PL leaves the last group without a partner to alternate with (the driver's
+            # --steps 20 at L = 8: 7 + 7 | 6 alone).  Prefer fewer, somewhat larger groups (20 -> 10 + 10) while they stay within
+            # 1.5 L; else one more round of smaller ones
+            lo = ng // PL * PL
+            ng = lo if lo >= PL and (len(items) + lo - 1) // lo <= min(31, L + L // 2) else min(lo + PL, len(items))
         sizes = [len(items) // ng + (1 if k < len(items) % ng else 0) for k in range(ng)] if ng else []
         starts = [sum(sizes[:k]) for k in range(ng)]
         for k in range(0, ng, PL):
@@ -648,7 +654,8 @@ def main():
 
     # untimed warm-up: at least one FULL lock-step group, so the timed region meets no first-use cost
     # (kernel attributes, resample tables, workspace growth) at its own batch sizes
-    n_warm = 0 if args.warmup <= 0 else max(args.warmup, min(args.lockstep, 31) * conc)
+    n_warm = 0 if args.warmup <= 0 else max(args.warmup, min(args.lockstep, 31) * conc,
+                                            min(min(args.lockstep, 31) * max(1, args.pipeline), 16) * conc)   # OWL: two full groups of 8
     # this rank's timed items: item id k * world + rank (item i -> rank i % world); the sampler seed is a function of the
     # item id only, so results do not depend on the rank count.  Videos are resident in HBM before the timer starts.
     items = [make_item(k * world + rank, 2025 + k * world + rank) for k in range(args.steps)]
