@@ -216,7 +216,16 @@ __global__ __launch_bounds__(256, MINW) void gemm_x3_v2(const float* __restrict_
     unsigned aoff[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) { int ar = m0 + r0 + 32 * i; ar = ar < M ? ar : M - 1; aoff[i] = (unsigned)(ar - m0) * (unsigned)K * 4u + c4 * 16; }
-    const char* abase = reinterpret_cast<const char*>(A + (size_t)m0 * K);
+    // STAGE == 3: A is given as three bf16 planes per row, [M][3][K] (what a producer -- LayerNorm, the attention / GELU epilogues --
+    // would write): staging is 16-byte loads + ds_write_b128, no split.  Thread -> 16-B chunk t & 3 of (plane, row) = idx / BM, idx % BM,
+    // idx = (t >> 2) + 64 i
+    constexpr int NPL = 3 * BM / 64, RPP = BM / 64;                 // pieces; row groups of 64 per plane
+    // piece i: plane i / RPP, row (t >> 2) + 64 (i % RPP): the swizzle term is the same for rows 64 apart, the plane term is uniform
+    unsigned prow[RPP];
+#pragma unroll
+    for (int i = 0; i < RPP; ++i) { int ar = m0 + (t >> 2) + 64 * i; ar = ar < M ? ar : M - 1; prow[i] = (unsigned)(ar - m0) * (unsigned)K * 6u + (t & 3) * 16; }
+    const int pwr0 = (t >> 2) * 64 + (((t & 3) ^ ((t >> 4) & 3)) << 4);
+    const char* abase = STAGE == 3 ? reinterpret_cast<const char*>(A) + (size_t)m0 * K * 6 : reinterpret_cast<const char*>(A + (size_t)m0 * K);
     const int nsteps = K / 16, nk = K / BK;
     // fragment stream of this wave's column tile j: (uniform base) + step * 3072 + ph * 1024 + lane * 16, ph = 2 - kw
     const char* wrow = Wp + (size_t)((n0 >> 5) + wn * TN) * nsteps * 3072;
@@ -235,6 +244,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_x3_v2(const float* __restrict_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[NA];
+    u32x4 rpl[NPL];
     u32x4 w[3][TN];                 // w[kw][j]: plane kw of column tile j, current step
     bf16x8 a0[2][TM], a1[TM], a2[TM];
 
@@ -244,6 +254,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_x3_v2(const float* __restrict_
     const __amdgpu_buffer_rsrc_t rw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wrow), 0, 0x7fffffff, 0x00020000);
     auto gloadA = [&](int kt) __attribute__((always_inline)) {
         kt = kt < nk ? kt : nk - 1;
+        if constexpr (STAGE == 3) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) rpl[i] = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, (int)prow[i % RPP], kt * (BK * 2) + (i / RPP) * K * 2, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, (int)aoff[i], kt * (BK * 4), 0));
@@ -259,6 +274,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_x3_v2(const float* __restrict_
     // staging piece p of NA * 2: half p & 1 of float4 p >> 1; the three 8-byte stores follow the second half
     unsigned sp[2][3];
     auto stage_piece = [&](auto P, char* wbase) __attribute__((always_inline)) {
+        if constexpr (STAGE == 3) {
+            constexpr int p3 = decltype(P)::value;
+            if constexpr (p3 < NPL) *reinterpret_cast<u32x4*>(wbase + pwr0 + (p3 / RPP) * A_T + (p3 % RPP) * 4096) = rpl[p3];
+            return;
+        }
         constexpr int p = decltype(P)::value, i = p >> 1, hf = p & 1;
         split2_rn3(ra[i][2 * hf], ra[i][2 * hf + 1], sp[hf]);
         if constexpr (hf == 1) {
@@ -277,11 +297,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_x3_v2(const float* __restrict_
     // wbase: where the next tile's planes are written (only S == 0 stages); gnext: fragment-stream step of the reloads
     auto step = [&](auto SS, const char* rbase, int roff, char* wbase, int gnext, int ktload) __attribute__((always_inline)) {
         constexpr int S = decltype(SS)::value;
-        constexpr int NPIECE = NA * 2;
+        constexpr int NPIECE = STAGE == 3 ? NPL : NA * 2;
         int grp = 0;                        // MFMA groups issued so far in this step (compile-time after unrolling)
         auto after_group = [&](auto G) __attribute__((always_inline)) {
             constexpr int g = decltype(G)::value;
-            if constexpr (S == 0 && STAGE == 0) {
+            if constexpr (S == 0 && STAGE != 1) {   // 0: split pieces interleaved, 3: plane copies interleaved
                 // NPIECE split pieces + the load of the tile after next, PPG of them per MFMA group
                 constexpr int NG = 6 * (TN / 2), PPG = (NPIECE + 1 + NG - 1) / NG;
                 [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_x3_v2(const float* __restrict_
     }(std::make_integer_sequence<int, TN>{});
     [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
         (stage_piece(std::integral_constant<int, P>{}, smem), ...);
-    }(std::make_integer_sequence<int, NA * 2>{});
+    }(std::make_integer_sequence<int, (STAGE == 3 ? NPL : NA * 2)>{});
     gloadA(1);
     __syncthreads();
 #pragma unroll
@@ -980,6 +1000,18 @@ static void pack_w(const float* W, int N, int K, std::vector<unsigned short>& ou
         }
 }
 
+// f32 [M][K] -> three bf16 planes per row, [M][3][K] (the producer-side split of STAGE == 3)
+__global__ void planes_kernel(const float* __restrict__ A, unsigned* __restrict__ P, size_t npairs, int K) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= npairs) return;
+    const size_t row = g / (K / 2); const int kp = (int)(g % (K / 2));
+    unsigned o[3];
+    split2_rn3(A[row * K + 2 * kp], A[row * K + 2 * kp + 1], o);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P[(row * 3 + k) * (K / 2) + kp] = o[k];
+}
+static unsigned* g_planes = nullptr;       // planes of the A matrix of the current test (main sets it before the variants run)
+
 template <class KERN>
 static float run(KERN k, int BM, int BN, const float* A, const char* Wp, float* C, int M, int N, int K, int iters, int nthr = 256) {
     const int lds = 2 * 3 * BM * 64;
@@ -1015,6 +1047,7 @@ int main(int argc, char** argv) {
     static const Var vars[] = {
         {"base 128x256 (library r4 loop)", 128, 256, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_base<2, 4, 2>, 128, 256, a, w, c, m, n, k, it); }},
         {"v2   128x256 staged interleaved", 128, 256, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_v2<2, 4, 2, 0, 0>, 128, 256, a, w, c, m, n, k, it); }},
+        {"v2   128x256 A as bf16 planes [M][3][K] (producer-side split)", 128, 256, [](const float*, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_v2<2, 4, 2, 3, 0>, 128, 256, reinterpret_cast<const float*>(g_planes), w, c, m, n, k, it); }},
         {"v2   128x256 staged lump", 128, 256, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_v2<2, 4, 2, 1, 0>, 128, 256, a, w, c, m, n, k, it); }},
         {"v2   128x256 interleaved + setprio", 128, 256, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_v2<2, 4, 2, 0, 1>, 128, 256, a, w, c, m, n, k, it); }},
         {"base 128x128", 128, 128, [](const float* a, const char* w, float* c, int m, int n, int k, int it) { return run(gemm_x3_base<2, 2, 2>, 128, 128, a, w, c, m, n, k, it); }},
@@ -1041,6 +1074,8 @@ int main(int argc, char** argv) {
         float* a2; CK(hipMalloc(&a2, a.size() * 4)); CK(hipMemcpy(a2, a.data(), a.size() * 4, hipMemcpyHostToDevice));
         pack_w(w.data(), n, k, pk); CK(hipMemcpy(Wp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
         std::vector<float> hC((size_t)m * n);
+        CK(hipMalloc(&g_planes, (size_t)m * k * 6));
+        hipLaunchKernelGGL(planes_kernel, dim3((unsigned)(((size_t)m * k / 2 + 255) / 256)), dim3(256), 0, 0, a2, g_planes, (size_t)m * k / 2, k);
         for (int v = 0; v < NV; ++v) {
             CK(hipMemset(C, 0xFF, hC.size() * 4));
             vars[v].fn(a2, Wp, C, m, n, k, 0);
@@ -1049,7 +1084,7 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < hC.size(); ++i) { const double e = hC[i] - ref[i]; maxe = fmax(maxe, fabs(e)); se += e * e; }
             printf("  K=%4d %-40s max|err| %.3e  rms err %.3e%s\n", k, vars[v].name, maxe, sqrt(se / hC.size()), (maxe < 1e-4 && maxe == maxe) ? "" : "   <-- WRONG");
         }
-        CK(hipFree(a2));
+        CK(hipFree(a2)); CK(hipFree(g_planes)); g_planes = nullptr;
     }
 
     // ---- speed on the B = 256 batch shapes (random operands unless `zero`)
@@ -1060,6 +1095,10 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * M * sh.N * sh.K;
         pack_w(hW.data(), sh.N, sh.K, pk); CK(hipMemcpy(Wp, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
         if (zero) CK(hipMemset(Wp, 0, pk.size() * 2));
+        if (g_planes) CK(hipFree(g_planes));
+        CK(hipMalloc(&g_planes, (size_t)M * sh.K * 6));
+        hipLaunchKernelGGL(planes_kernel, dim3((unsigned)(((size_t)M * sh.K / 2 + 255) / 256)), dim3(256), 0, 0, A, g_planes, (size_t)M * sh.K / 2, sh.K);
+        CK(hipDeviceSynchronize());
         for (int rep = 0; rep < (only ? 1 : 2); ++rep)
             for (int v = 0; v < NV; ++v) {
                 if (only && !strstr(vars[v].name, only)) continue;
