@@ -212,6 +212,20 @@ def grid4_record(heuristic, store, nframes, k):
                           "(tstar_amd.lockstep._Group.speculate: -3 %), split-K for the M = 577 launches would change bits with the batch size and is not used"}
 
 
+def lockstep_group_sizes(n, L, PL):
+    """Sizes of the lock-step groups `n` items are run in: groups of at most about L items, balanced (5 items at L = 4 -> 3 + 2, not
+    4 + 1), their count a multiple of the alternation depth PL when n allows it -- a count that is not leaves the last group without a
+    partner to alternate with (the driver's --steps 20 at L = 8 ran 7 + 7 alternating, then 6 alone).  Fewer, somewhat larger groups
+    are preferred (20 -> 10 + 10) while they stay within 1.5 L and 31 items; else one more round of smaller ones."""
+    if n <= 0:
+        return []
+    ng = (n + L - 1) // L
+    if PL > 1 and ng % PL and n > 1:
+        lo = ng // PL * PL
+        ng = lo if lo >= PL and (n + lo - 1) // lo <= min(31, L + L // 2) else min(lo + PL, n)
+    return [n // ng + (1 if k < n % ng else 0) for k in range(ng)]
+
+
 def cpu_baseline(args, stats):
     """Reference-faithful CPU path (oracle = "port") on the host cores: one grid call and a few
     verification calls are timed, then extrapolated to the GPU run's call mix."""
@@ -611,14 +625,8 @@ def main():
             PL -= 1
         # groups of at most L items, balanced (5 items at L = 4 -> 3 + 2, not 4 + 1); PL consecutive groups alternate on the
         # GPU (tstar_amd.lockstep)
-        ng = (len(items) + L - 1) // L
-        if PL > 1 and ng % PL and len(items) > 1:
-            # a group count that is not a multiple of PL leaves the last group without a partner to alternate with (the driver's
-            # --steps 20 at L = 8: 7 + 7 | 6 alone).  Prefer fewer, somewhat larger groups (20 -> 10 + 10) while they stay within
-            # 1.5 L; else one more round of smaller ones
-            lo = ng // PL * PL
-            ng = lo if lo >= PL and (len(items) + lo - 1) // lo <= min(31, L + L // 2) else min(lo + PL, len(items))
-        sizes = [len(items) // ng + (1 if k < len(items) % ng else 0) for k in range(ng)] if ng else []
+        sizes = lockstep_group_sizes(len(items), L, PL)
+        ng = len(sizes)
         starts = [sum(sizes[:k]) for k in range(ng)]
         for k in range(0, ng, PL):
             q.put((starts[k], [items[starts[j]:starts[j] + sizes[j]] for j in range(k, min(k + PL, ng))]))

@@ -616,6 +616,23 @@ def test_spline_worker_count_follows_the_affinity_mask(monkeypatch):
     assert SP.default_workers() == 3
 
 
+def test_bench_lockstep_group_sizes():
+    """bench.lockstep_group_sizes: every item in exactly one group, balanced sizes, a group count that is a multiple of the alternation
+    depth whenever there are at least that many items (the driver's --steps 20: 10 + 10, not 7 + 7 | 6)."""
+    import bench
+    assert bench.lockstep_group_sizes(20, 8, 2) == [10, 10] and bench.lockstep_group_sizes(16, 8, 2) == [8, 8]
+    assert bench.lockstep_group_sizes(5, 8, 2) == [3, 2] and bench.lockstep_group_sizes(1, 8, 2) == [1] and bench.lockstep_group_sizes(0, 8, 2) == []
+    assert bench.lockstep_group_sizes(25, 8, 2) == [7, 6, 6, 6] and bench.lockstep_group_sizes(5, 4, 1) == [3, 2]
+    for n in range(1, 140):
+        for L in (1, 4, 8, 24, 31):
+            for PL in (1, 2, 3):
+                sz = bench.lockstep_group_sizes(n, L, PL)
+                assert sum(sz) == n and min(sz) >= 1 and max(sz) - min(sz) <= 1, (n, L, PL, sz)
+                assert max(sz) <= max(L + L // 2, 1) or max(sz) <= 31, (n, L, PL, sz)
+                if n >= PL and PL > 1 and n > 1:
+                    assert len(sz) % PL == 0 or len(sz) == n, (n, L, PL, sz)
+
+
 def test_bench_self_spawn_command(monkeypatch):
     """`python bench.py --gpus N` typed without a launcher (WORLD_SIZE unset) starts its own ranks: the command is the driver's
     (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1, the user's flags passed through), launcher variables of
