@@ -204,12 +204,13 @@ def grid4_record(heuristic, store, nframes, k):
             "solo_sec_per_video": t_solo, "solo_frames_per_s": solo[0][0].frames_scored / t_solo,
             "grid_calls_per_video": sum(s_.iterations for s_, _ in grp) / nv,
             "verify_calls_per_video": sum(s_.detector_calls - s_.iterations for s_, _ in grp) / nv,
-            "solo_bound": "GPU kernels cover ~82-99 % of a solo search (profiles/r05_solo_grid4_gaps.txt: 643 ms of kernels in a 650 ms search; "
-                          "under the tracer the remaining idle is the host FITPACK fit of the LATE iterations, ~800 knots, 3-7 ms, outlasting the "
-                          "verification forward it overlaps); the kernels themselves run at small batch: a B = 1 grid forward (M = 577) and a "
-                          "B ~ 10 verification forward per iteration, 63 iterations, 670 detector images at ~1 ms each against 0.55 ms in the "
-                          "lock-step bench.  The next iteration's grid forward is queued speculatively behind each verification batch "
-                          "(tstar_amd.lockstep._Group.speculate: -3 %), split-K for the M = 577 launches would change bits with the batch size and is not used"}
+            "solo_bound": "GPU kernels are ~0.59 s of a 0.58 s search without the tracer / 81 % of the traced window (profiles/r05_solo_grid4_gaps.txt; "
+                          "under the tracer the idle is the host FITPACK fit of the LATE iterations, ~800 knots, outlasting the verification "
+                          "forward it overlaps); the kernels run at small batch: a B = 1 grid forward (M = 577, 2.06 ms: 456-1824 wave tiles for "
+                          "1024 SIMDs) and a B ~ 10 verification forward per iteration, 63 iterations, 670 detector images at ~0.9 ms each against "
+                          "0.55 ms in the lock-step bench.  The next iteration's grid forward is queued speculatively behind each verification batch "
+                          "(tstar_amd.lockstep._Group.speculate), the 64x64 tile keeps the weight fragments of four K = 16 steps in flight "
+                          "(csrc/gemm_f32.hip); split-K for the M = 577 launches would change bits with the batch size and is not used"}
 
 
 def lockstep_group_sizes(n, L, PL):

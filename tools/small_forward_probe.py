@@ -2,7 +2,7 @@
 events.  Under `rocprofv3 --kernel-trace` + tools/rocpd_gaps.py it shows how much of that wall time is idle GPU between the
 ~100 dependent launches of one forward -- the only thing a hipGraph could remove.
 
-    python tools/small_forward_probe.py [forwards per batch size, default 40]
+    python tools/small_forward_probe.py [forwards per batch size, default 40] [weights mode: f32 (default) | f32x3 | ...]
 """
 import os
 import sys
@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tstar_amd.interface_heuristic import OWLInterface
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-h = OWLInterface(synthetic_seed=0, max_batch=8, device="cuda:0")
+mode = sys.argv[2] if len(sys.argv) > 2 else "f32"
+h = OWLInterface(synthetic_seed=0, max_batch=8, device="cuda:0", weights_dtype=mode)
+print("weights mode", mode)
 h.reparameterize_object_list(["couch"], ["tv"])
 g = torch.Generator(device="cpu").manual_seed(0)
 for B in (1, 4):

@@ -471,6 +471,11 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
     constexpr int A_T = BM * 64, BUF = 3 * A_T;                           // bytes: one plane, one buffer (three planes)
     constexpr int NA = BM / 32;                                           // float4 loads per thread per K tile
     constexpr int PAIR = TN >= 2 ? 2 : 1, GP = TN / PAIR;                 // column tiles interleaved, groups of them
+    // weight-fragment prefetch distance in K = 16 steps.  One step is 6 * TM * TN MFMAs: 48 (1500+ cycles) on the batch tiles, but only 6
+    // (~190 cycles, a fraction of the L2 latency) on the 64x64 tile of the M = 577 launches, whose 120-480 blocks cannot hide it by
+    // occupancy either -- there the fragments of FOUR steps are in flight (a ring of 4 slot sets, the loop unrolled by two K tiles).
+    // Same MFMA order per accumulator: same bits.
+    constexpr int WD = TM * TN == 1 ? 4 : 1;                              // (2 on the 64x128 / 128x128 tiles measured no different: r05_x3_cfg_sweep_small_m_prefetch.log)
     static_assert(TN % PAIR == 0, "column tiles go in pairs");
     char* smem = reinterpret_cast<char*>(smem_f);
     const int t = threadIdx.x;
@@ -507,7 +512,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[NA];
-    u32x4 w[3][TN];                                                       // w[kw][j]: plane kw of column tile j, current step
+    u32x4 w[WD][3][TN];                                                   // w[slot][kw][j]: plane kw of column tile j; slot = step % WD
     bf16x8 a0[2][TM], a1[TM], a2[TM];
     unsigned sp[2][3];
 
@@ -517,10 +522,10 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
         for (int i = 0; i < NA; ++i)
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, (int)aoff[i], kt * (BK * 4), 0));
     };
-    auto wload = [&](auto KW, auto J, int gs) __attribute__((always_inline)) {
-        constexpr int kw = decltype(KW)::value, j = decltype(J)::value;
+    auto wload = [&](auto SL, auto KW, auto J, int gs) __attribute__((always_inline)) {
+        constexpr int sl = decltype(SL)::value, kw = decltype(KW)::value, j = decltype(J)::value;
         gs = gs < nsteps ? gs : nsteps - 1;
-        w[kw][j] = __builtin_amdgcn_raw_buffer_load_b128(rw_rsrc, voff + (2 - kw) * 1024, (j * nsteps + gs) * 3072, 0);
+        w[sl][kw][j] = __builtin_amdgcn_raw_buffer_load_b128(rw_rsrc, voff + (2 - kw) * 1024, (j * nsteps + gs) * 3072, 0);
     };
     auto rd_a = [&](const char* base, int off, int plane, int i) __attribute__((always_inline)) {
         return *reinterpret_cast<const bf16x8*>(base + off + plane * A_T + i * 2048);
@@ -543,8 +548,10 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
     // one K = 16 step.  S = step inside the tile (selects the a0 set); rbase / roff: where the NEXT step's fragments are read;
     // wbase: where the next tile's planes go (only S == 0 stages); gnext: fragment-stream step of the reloads; ktload: the tile
     // whose activations are loaded once the staging registers are free
-    auto step = [&](auto SS, const char* rbase, int roff, char* wbase, int gnext, int ktload) __attribute__((always_inline)) {
+    auto step = [&](auto SS, auto SLOT, const char* rbase, int roff, char* wbase, int gnext, int ktload) __attribute__((always_inline)) {
         constexpr int S = decltype(SS)::value;
+        using SL = decltype(SLOT);
+        auto& ws = w[SL::value];                                          // this step's fragments; each is reloaded (step gnext) after its last product
         constexpr int NPIECE = NA * 2, NG = 6 * GP, PPG = (NPIECE + 1 + NG - 1) / NG;
         auto after_group = [&](auto G) __attribute__((always_inline)) {
             constexpr int gi = decltype(G)::value;
@@ -570,19 +577,19 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
 #pragma unroll
                 for (int jj = 0; jj < PAIR; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) mf(a2[i], w[0][j0 + jj], acc[i][j0 + jj]);
+                    for (int i = 0; i < TM; ++i) mf(a2[i], ws[0][j0 + jj], acc[i][j0 + jj]);
                 after_group(std::integral_constant<int, 3 * JP + 0>{});
 #pragma unroll
                 for (int jj = 0; jj < PAIR; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) mf(a1[i], w[0][j0 + jj], acc[i][j0 + jj]);
+                    for (int i = 0; i < TM; ++i) mf(a1[i], ws[0][j0 + jj], acc[i][j0 + jj]);
                 after_group(std::integral_constant<int, 3 * JP + 1>{});
 #pragma unroll
                 for (int jj = 0; jj < PAIR; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[0][j0 + jj], acc[i][j0 + jj]);
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], ws[0][j0 + jj], acc[i][j0 + jj]);
                 [&]<int... JJ>(std::integer_sequence<int, JJ...>) __attribute__((always_inline)) {
-                    (wload(std::integral_constant<int, 0>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
+                    (wload(SL{}, std::integral_constant<int, 0>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
                 }(std::make_integer_sequence<int, PAIR>{});
                 after_group(std::integral_constant<int, 3 * JP + 2>{});
             }(), ...);
@@ -598,14 +605,14 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
 #pragma unroll
                 for (int jj = 0; jj < PAIR; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) mf(a1[i], w[1][j0 + jj], acc[i][j0 + jj]);
+                    for (int i = 0; i < TM; ++i) mf(a1[i], ws[1][j0 + jj], acc[i][j0 + jj]);
                 after_group(std::integral_constant<int, 3 * GP + 2 * JP + 0>{});
 #pragma unroll
                 for (int jj = 0; jj < PAIR; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[1][j0 + jj], acc[i][j0 + jj]);
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], ws[1][j0 + jj], acc[i][j0 + jj]);
                 [&]<int... JJ>(std::integer_sequence<int, JJ...>) __attribute__((always_inline)) {
-                    (wload(std::integral_constant<int, 1>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
+                    (wload(SL{}, std::integral_constant<int, 1>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
                 }(std::make_integer_sequence<int, PAIR>{});
                 after_group(std::integral_constant<int, 3 * GP + 2 * JP + 1>{});
             }(), ...);
@@ -620,9 +627,9 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
 #pragma unroll
                 for (int jj = 0; jj < PAIR; ++jj)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[2][j0 + jj], acc[i][j0 + jj]);
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], ws[2][j0 + jj], acc[i][j0 + jj]);
                 [&]<int... JJ>(std::integer_sequence<int, JJ...>) __attribute__((always_inline)) {
-                    (wload(std::integral_constant<int, 2>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
+                    (wload(SL{}, std::integral_constant<int, 2>{}, std::integral_constant<int, j0 + JJ>{}, gnext), ...);
                 }(std::make_integer_sequence<int, PAIR>{});
                 after_group(std::integral_constant<int, 5 * GP + JP>{});
             }(), ...);
@@ -631,11 +638,11 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
 
     // ---- prologue: tile 0 into LDS buffer 0, step 0's weight fragments, tile 1 into the staging registers
     gload_a(0);
-    [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
-        ((wload(std::integral_constant<int, 0>{}, std::integral_constant<int, J>{}, 0),
-          wload(std::integral_constant<int, 1>{}, std::integral_constant<int, J>{}, 0),
-          wload(std::integral_constant<int, 2>{}, std::integral_constant<int, J>{}, 0)), ...);
-    }(std::make_integer_sequence<int, TN>{});
+    [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {      // steps 0 .. WD - 1 into their slots
+        ((wload(std::integral_constant<int, Q / TN>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, Q % TN>{}, Q / TN),
+          wload(std::integral_constant<int, Q / TN>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, Q % TN>{}, Q / TN),
+          wload(std::integral_constant<int, Q / TN>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, Q % TN>{}, Q / TN)), ...);
+    }(std::make_integer_sequence<int, WD * TN>{});
     [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
         (stage_piece(std::integral_constant<int, P>{}, smem), ...);
     }(std::make_integer_sequence<int, NA * 2>{});
@@ -646,16 +653,28 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& g, const int m0, co
     // one static priority for the whole loop (over a co-resident block's prologue / epilogue): +1 % in the lab
     __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_sched_barrier(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K tile: step 0 (the next fragments are this tile's step 1; stages tile kt + 1 into the other buffer, then loads tile kt + 2),
+    // the barrier, step 1 (the next fragments are tile kt + 1, step 0).  SL0 = slot of the tile's first step
+    auto tile = [&](auto SL0, int kt) __attribute__((always_inline)) {
+        constexpr int s0 = decltype(SL0)::value;
         char* cur = smem + (kt & 1) * BUF;
         char* nxt = smem + ((kt + 1) & 1) * BUF;
-        // step 0: the next fragments are this tile's step 1; stages tile kt + 1 into the other buffer, then loads tile kt + 2
-        step(std::integral_constant<int, 0>{}, cur, rd1, nxt, 2 * kt + 1, kt + 2);
+        step(std::integral_constant<int, 0>{}, std::integral_constant<int, s0>{}, cur, rd1, nxt, 2 * kt + WD, kt + 2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // step 1: the next fragments are tile kt + 1, step 0
-        step(std::integral_constant<int, 1>{}, nxt, rd0, nxt, 2 * kt + 2, 0);
+        step(std::integral_constant<int, 1>{}, std::integral_constant<int, (s0 + 1) % WD>{}, nxt, rd0, nxt, 2 * kt + 1 + WD, 0);
+    };
+    if constexpr (WD <= 2) {
+        for (int kt = 0; kt < nk; ++kt) tile(std::integral_constant<int, 0>{}, kt);      // a tile's two steps are slots 0 and (WD == 2) 1
+    } else {
+        static_assert(WD == 4, "the loop below is unrolled by WD / 2 = 2 K tiles");
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            tile(std::integral_constant<int, 0>{}, kt);
+            tile(std::integral_constant<int, 2>{}, kt + 1);
+        }
+        if (kt < nk) tile(std::integral_constant<int, 0>{}, kt);          // odd tile count: kt is even, its steps are slots 0 and 1
     }
     __builtin_amdgcn_s_setprio(0);
     gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
