@@ -174,7 +174,8 @@ def test_gemm_bf16_weights_two_term(lib, M, N, K, act, res):
 
 @pytest.mark.parametrize("M,N,K,act,res", [(577, 768, 3072, 0, False), (130, 256, 64, 1, False), (1154, 512, 768, 2, False),
                                            (25388, 768, 768, 0, True), (29427, 2304, 768, 0, False), (30004, 768, 3072, 0, True),
-                                           (23657, 3072, 768, 1, False), (1, 128, 32, 0, False)])
+                                           (23657, 3072, 768, 1, False), (1, 128, 32, 0, False),
+                                           (577, 128, 96, 0, False), (70, 256, 160, 0, True)])   # odd K-tile counts: the peeled tile of the 64x64 ring
 def test_gemm_f32x3(lib, M, N, K, act, res):
     """f32x3 GEMM (weights_mode 4, round 4): both f32 operands as THREE exact round-to-nearest bf16 terms (all 24 significand
     bits), the six partial products with ka + kw <= 2 on the bf16 matrix pipe, f32 accumulation.  The gate the round-3 review
