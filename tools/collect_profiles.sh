@@ -69,6 +69,7 @@ $PY > "$OUT/${TAG}_bench.json" 2>> "$OUT/bench.err"
 rm -rf /tmp/prof_sf
 rocprofv3 --kernel-trace -d /tmp/prof_sf -o sf -- python $ROOT/tools/small_forward_probe.py 40 > "$OUT/${TAG}_small_forward_probe.log" 2>&1
 python $ROOT/tools/rocpd_gaps.py "$(find /tmp/prof_sf -name '*.db' | head -1)" 0.9 > "$OUT/${TAG}_small_forward_idle_gaps.txt"
+python $ROOT/tools/small_forward_probe.py 40 f32x3 2>&1 | grep -v amdgpu.ids >> "$OUT/${TAG}_small_forward_probe.log"      # the bench's mode (the traced run above is the library default, f32)
 [ -x $ROOT/tools/lab/pkfma_rate ] && $ROOT/tools/lab/pkfma_rate > "$OUT/${TAG}_valu_pkfma_rate.log" 2>&1
 python $ROOT/tools/bench_gemm_cfg.py > "$OUT/${TAG}_gemm_tile_configs.log" 2>&1
 python $ROOT/tools/sweep_small_m.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_gemm_subwave_sweep.log"
