@@ -32,7 +32,7 @@ cd /tmp
 #    verification, config.grid4 -- run too; the timed region is cut out of the trace at the marker kernels bench.py
 #    enqueues around it, tools/rocpd_window.py)
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $PY --steps 8 --warmup 1 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/rocprof_kt.err"
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $PY --steps 16 --warmup 1 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/rocprof_kt.err"
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 BJ="$OUT/${TAG}_bench_under_rocprofv3.json"
 python $ROOT/tools/rocpd_stats.py "$DB" > "$OUT/${TAG}_rocprofv3_kernel_stats.md"
@@ -48,9 +48,10 @@ python $ROOT/tools/rocpd_gaps.py "$DB" --timed-region "$BJ" > "$OUT/${TAG}_gpu_i
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES"; do
     N=$(echo $C | tr ' ' '_')
     rm -rf /tmp/prof_$N
+    # --steps 16: the default line's own launch population (two lock-step groups of 8), so that bytes per launch compare like with like;
     # --no-grid4 --no-verify: every GEMM dispatch of the run is one of the timed steps' (plus the text tower's 48 tiny ones),
     # so the per-launch averages are over the same population as the bench line's avg_launch_gflop
-    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify --no-other-configs > /dev/null 2> "$OUT/rocprof_$N.err"
+    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 16 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify --no-other-configs > /dev/null 2> "$OUT/rocprof_$N.err"
 done
 F=$(find /tmp/prof_FETCH_SIZE -name '*.db' | head -1)
 W=$(find /tmp/prof_WRITE_SIZE -name '*.db' | head -1)
