@@ -29,7 +29,7 @@ def main(fetch_db, write_db, sub, command=None):
            "bytes_per_launch_corrected": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
            "bytes_per_launch_uncorrected": (f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
            "correction": "FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KiB units",
-           "command": command or "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify "
+           "command": command or "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --steps 16 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify "
                       "(tools/collect_profiles.sh)"}
     print(json.dumps(out, indent=1))
 
