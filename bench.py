@@ -115,6 +115,10 @@ def parse():
                          "itself three more times -- configs[3] (YOLO-World, 48 steps), configs[4] (bf16 weights, 14400 frames, K = 32, grid 15) "
                          "and configs[1] on the native f32 MFMA tiles (config.f32_native) -- and embeds value / roofline / keyframes_verified of each, so that the driver "
                          "observes them too (about +70 s, none of it inside the timed region)")
+    ap.add_argument("--no-drop-in", action="store_true",
+                    help="skip config.drop_in: what a user of the UNCHANGED TStarFramework gets -- the heuristic default-constructed by "
+                         "initialize_heuristic('owl-vit') (mode from TSTAR_WEIGHTS_DTYPE), ONE search alone at the reference's 4x4 grid, K = 8, "
+                         "visual history ON, the process-global numpy generator -- in the native-f32 and the f32x3 mode (about +8 s, untimed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["full", "sample"], default="full",
                     help="full (default) = besides the sampled figure, ONE complete reference-faithful search of the workload is run and MEASURED on the "
@@ -213,6 +217,58 @@ def grid4_record(heuristic, store, nframes, k):
                           "(csrc/gemm_f32.hip); split-K for the M = 577 launches would change bits with the batch size and is not used"}
 
 
+def drop_in_record(store, k):
+    """What the 2-line import swap of INTEGRATION.md gives an UNCHANGED ``TStarFramework`` (review item 1b of round 5), outside the timed region:
+    the heuristic built by the reference's own call ``initialize_heuristic("owl-vit")`` -- no keyword arguments (TStarFramework.py:171-187, 207); the
+    arithmetic mode comes from ``TSTAR_WEIGHTS_DTYPE``, the offline stand-in for the checkpoint from ``TSTAR_SYNTHETIC_SEED`` -- and the searcher built
+    with the keywords of TStarFramework.py:97-107 at ITS defaults (4x4 grid, K = 8, threshold 0.6, budget 1000): ONE search alone, the visual history
+    kept (image_grid_iters / detect_annotot_iters filled, as TStarFramework reads them at :152-157), the process-global numpy generator."""
+    import torch
+    from tstar_amd.interface_heuristic import initialize_heuristic
+    from tstar_amd.interface_searcher import TStarSearcher
+    saved = {k_: os.environ.get(k_) for k_ in ("TSTAR_WEIGHTS_DTYPE", "TSTAR_SYNTHETIC_SEED", "TSTAR_MAX_BATCH")}
+    out = {"what": "initialize_heuristic('owl-vit') with no keyword arguments + TStarSearcher(video_path=, target_objects=, cue_objects=, search_nframes=8, "
+                   "image_grid_shape=(4, 4), output_dir=, confidence_threshold=0.6, search_budget=1000, heuristic=): ONE search alone, visual history ON, "
+                   "global numpy generator seeded once (np.random.seed(2025)); mode selected by TSTAR_WEIGHTS_DTYPE (unset = f32)",
+           "grid": "4x4 (16 frames/iter, the reference default)"}
+    try:
+        for mode in ("f32", "f32x3"):
+            os.environ["TSTAR_SYNTHETIC_SEED"] = "0"
+            os.environ.pop("TSTAR_MAX_BATCH", None)
+            if mode == "f32":
+                os.environ.pop("TSTAR_WEIGHTS_DTYPE", None)           # the library default
+            else:
+                os.environ["TSTAR_WEIGHTS_DTYPE"] = mode
+            h = initialize_heuristic("owl-vit")
+            assert h.weights_dtype == mode
+
+            def one(seed):
+                np.random.seed(seed)
+                s_ = TStarSearcher(video_path=store, target_objects=list(TARGETS), cue_objects=list(CUES), search_nframes=k, image_grid_shape=(4, 4),
+                                   output_dir=None, confidence_threshold=0.6, search_budget=1000, heuristic=h)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                frames, ts = s_.search()
+                torch.cuda.synchronize()
+                return s_, [float(t) for t in ts], time.perf_counter() - t0
+
+            one(1)                                                      # first-use costs of this handle's shapes
+            s_, ts, dt = one(2025)
+            out[mode] = {"sec_per_video": dt, "frames_per_s": s_.frames_scored / dt, "frames_scored": s_.frames_scored, "grid_calls": s_.iterations,
+                         "verify_calls": s_.detector_calls - s_.iterations, "history_entries": len(s_.image_grid_iters), "keyframes": ts,
+                         "max_batch": h.scorer.max_batch, "env": {"TSTAR_WEIGHTS_DTYPE": os.environ.get("TSTAR_WEIGHTS_DTYPE")}}
+            del s_, h
+            torch.cuda.empty_cache()
+    finally:
+        for k_, v in saved.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+    out["sec_per_video"] = out["f32x3"]["sec_per_video"]
+    return out
+
+
 def lockstep_group_sizes(n, L, PL):
     """Sizes of the lock-step groups `n` items are run in: groups of at most about L items, balanced (5 items at L = 4 -> 3 + 2, not
     4 + 1), their count a multiple of the alternation depth PL when n allows it -- a count that is not leaves the last group without a
@@ -285,6 +341,7 @@ def cpu_baseline(args, stats):
     t_ver /= max(nv, 1)
     per_video = stats["grid_calls"] * t_grid + stats["verify_calls"] * t_ver
     frames_scored = stats["grid_calls"] * n + stats["verify_calls"]
+    png = png_write_cost(grid_img, ver_imgs[0])
     # CPU(O) of SURVEY 8d: the same restatement with this build's own call structure (text tower cached,
     # verification frames batched) -- what the CPU does when only the arithmetic, not the reference's call
     # pattern, is kept
@@ -316,7 +373,10 @@ def cpu_baseline(args, stats):
         call(det, grid4_img, 4, 4)
         t_g4 = time.perf_counter() - t0
         pv4 = g4["grid_calls_per_video"] * t_g4 + g4["verify_calls_per_video"] * t_ver
+        png4 = png_write_cost(grid4_img, ver_imgs[0])
+        t_png4 = g4["grid_calls_per_video"] * png4["grid"] + g4["verify_calls_per_video"] * png4["verify"]
         grid4 = {"value": (g4["grid_calls_per_video"] * 16 + g4["verify_calls_per_video"]) / pv4, "unit": "frames/s", "sec_per_video": pv4,
+                 "png_write_sec_per_call": png4, "with_png_sec_per_video": pv4 + t_png4,
                  "sample": f"1 grid call (16 frames, {t_g4:.3f} s) + the verification calls timed above ({t_ver:.3f} s each), extrapolated to "
                            f"{g4['grid_calls_per_video']:.1f} grid + {g4['verify_calls_per_video']:.1f} verification calls per video"}
     return {
@@ -327,10 +387,36 @@ def cpu_baseline(args, stats):
                   f"{best_nt} torch threads (fastest of 8/16/32/64/{nt_all} on this host); "
                   f"the cv2.resize steps (not importable here) are prepared untimed",
         "sec_per_video": per_video, "grid4": grid4,
+        # the reference's per-call debug PNG (interface_heuristic.py:248-256) reported SEPARATELY, never part of `value`
+        "png_write_sec_per_call": png,
+        "decode_note": "the reference re-opens the video with decord.VideoReader on EVERY read_frame_batch call (interface_searcher.py:168) and decodes the "
+                       "sampled frames on the CPU; neither the re-open nor the decode is in this baseline (decord is not importable here and the frames are "
+                       "synthesised off the clock, as they are resident in HBM before the GPU timer starts): both omissions favour the CPU figure",
         "own_batching": {"value": frames_scored / per_video_o, "unit": "frames/s", "sec_per_video": per_video_o,
                          "sample": f"1 grid call ({t_grid_o:.3f} s, cached query embeddings) + verification forwards of {vb} "
                                    f"frame(s) ({t_ver_o:.3f} s per frame; best of batch 1 and 8), same extrapolation"},
     }
+
+
+def png_write_cost(grid_img, ver_img):
+    """Seconds per call of the reference's unconditional debug block (interface_heuristic.py:248-256): ``Image.fromarray(annotated_image[:, :, ::-1])
+    .save("./annotated_image.png")`` of the image every detector call scored -- the grid image (95 g x 200 g) or one 600x285 verification frame --
+    with Pillow's default PNG settings, into a scratch directory.  Best of three writes each."""
+    import tempfile
+    from PIL import Image
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "annotated_image.png")
+        for name, img in (("grid", grid_img), ("verify", ver_img)):
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                Image.fromarray(img[:, :, ::-1]).save(path)
+                t_ = time.perf_counter() - t0
+                best = t_ if best is None or t_ < best else best
+            out[name] = best
+            out[name + "_image"] = f"{img.shape[1]}x{img.shape[0]}"
+    return out
 
 
 def cpu_baseline_full(args, seed, nthreads, deadline_s=150.0):
@@ -479,7 +565,7 @@ def other_configs():
            and not k.startswith("TSTAR_")}
     for name, flags in runs.items():
         t1 = time.perf_counter()
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--warmup", "1", "--no-cpu-baseline", "--no-grid4", "--no-other-configs"] + flags
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--warmup", "1", "--no-cpu-baseline", "--no-grid4", "--no-other-configs", "--no-drop-in"] + flags
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -490,7 +576,8 @@ def other_configs():
             out[name] = {"value": j["value"], "unit": j["unit"], "steps": j["steps"], "ms_per_step": j["ms_per_step"], "dtype": j["dtype"],
                          "sec_per_video": j["config"]["sec_per_video"], "single_search_alone_latency_sec": j["config"]["single_search_alone_latency_sec"],
                          "keyframes_verified": j["config"]["keyframes_verified"], "host_cpu_sec_per_video": j["config"]["host_cpu_sec_per_video"],
-                         "roofline": {k: j["roofline"].get(k) for k in ("kernel", "bound", "achieved", "achieved_algorithmic", "peak", "unit", "frac", "time_share_of_step")},
+                         "roofline": {k: j["roofline"].get(k) for k in ("kernel", "bound", "achieved", "achieved_algorithmic", "peak", "unit", "frac", "frac_algorithmic", "executed_over_algorithmic",
+                                                                            "scheme_ceiling_tflops", "time_share_of_step")},
                          "workload": j["config"]["workload"], "command": "python bench.py " + " ".join(cmd[2:]), "wall_s": time.perf_counter() - t1}
         except Exception as e:                                  # a sub-run must never take the headline line down
             out[name] = {"error": repr(e)}
@@ -733,12 +820,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, frames_all, images_all = tmax[0].item(), t[1].item(), t[2].item()
-        hc = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
-        dist.all_gather(hc, torch.tensor([host_cpu / max(args.steps, 1)], dtype=torch.float64, device=cdev))
-        host_cpu_by_rank = [float(x.item()) for x in hc]
+        free_b, total_b = torch.cuda.mem_get_info()
+        hc = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(hc, torch.tensor([host_cpu / max(args.steps, 1), (total_b - free_b) / 2 ** 30], dtype=torch.float64, device=cdev))
+        host_cpu_by_rank = [float(x[0].item()) for x in hc]
+        hbm_by_rank = [float(x[1].item()) for x in hc]
     else:
         frames_all, images_all = float(frames), float(images)
         host_cpu_by_rank = [host_cpu / max(args.steps, 1)]
+        free_b, total_b = torch.cuda.mem_get_info()
+        hbm_by_rank = [(total_b - free_b) / 2 ** 30]
 
     # roofline of the dominant kernel (gemm_f32_kernel): HIP events on the launch stream, this rank
     n_l, ms, fl = C.c_longlong(0), C.c_double(0), C.c_double(0)
@@ -761,33 +852,49 @@ def main():
     # HBM-side traffic of the same kernel: rocprofv3 PMC passes of this command cannot run inside the
     # timed process, so the per-launch figure measured with `tools/rocpd_traffic.py` is read from the
     # committed summary (profiles/); None if it has not been collected.
-    traffic, traffic_src = None, None
-    # the newest collection of THIS mode wins (tools/collect_profiles.sh); files without a mode suffix are the native-f32 kernels'
-    sfx = {"f32": "", "f32x3": "_f32x3", "bf16": "_bf16", "bf16_exact": "_bf16_exact"}[args.weights]
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
-        tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_gemm_traffic{sfx}.json")
-        if os.path.isfile(tp):
+    # The figure is quoted ONLY when that collection ran this run's launch population (same flags that shape the launches, and its
+    # own algorithmic bytes per launch within 5 % of this run's): a per-launch byte count of one population divided by another's
+    # algorithmic bytes is not a ratio of anything (round 5 printed 0.28x ... 1.83x that way).
+    population = {"heuristic": args.heuristic, "weights": (args.weights if args.heuristic == "owl" else "f32-valu"), "steps": args.steps,
+                  "lockstep": max(1, min(args.lockstep, 31)), "pipeline": max(1, args.pipeline),
+                  "max_batch": args.yolo_max_batch if args.heuristic == "yolo" else args.max_batch, "grid": args.grid, "nframes": args.nframes,
+                  "search_nframes": args.search_nframes, "workload_kind": workload, "n_gpus": world, "concurrency": conc}
+    alg_bytes_run = by.value / max(n_l.value, 1)
+
+    def read_traffic(pattern):
+        """-> (bytes per launch, bytes / the collection's own algorithmic bytes, source file, note)"""
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
+            tp = os.path.join(ROOT, "profiles", pattern.format(tag=tag))
+            if not os.path.isfile(tp):
+                continue
+            rel = os.path.relpath(tp, ROOT)
             try:
-                tj = json.load(open(tp))
-                traffic, traffic_src = tj["bytes_per_launch_corrected"], f"profiles/{tag}_pmc_gemm_traffic{sfx}.json"
-                break
-            except Exception:
-                pass
+                with open(tp) as f:
+                    tj = json.load(f)
+            except Exception as e:
+                return None, None, rel, f"unreadable: {e!r}"
+            pop, ab = tj.get("population"), tj.get("algorithmic_bytes_per_launch")
+            if not pop or not ab:
+                return None, None, rel, "the newest PMC collection predates round 6 and does not record its launch population: not comparable"
+            diff = sorted(k_ for k_ in population if pop.get(k_) != population[k_])
+            if diff:
+                return None, None, rel, ("launch population differs from the PMC collection's in " +
+                                         ", ".join(f"{k_} ({population[k_]!r} here, {pop.get(k_)!r} there)" for k_ in diff))
+            if not alg_bytes_run or abs(ab / alg_bytes_run - 1.0) > 0.05:
+                return None, None, rel, f"algorithmic bytes per launch differ: {alg_bytes_run:.4g} here, {ab:.4g} in the PMC collection"
+            return tj["bytes_per_launch_corrected"], tj["bytes_per_launch_corrected"] / ab, rel, "same launch population as this run"
+        return None, None, None, "no PMC collection under profiles/"
+
+    # the newest collection of THIS mode (tools/collect_profiles.sh); files without a mode suffix are the native-f32 kernels'
+    sfx = {"f32": "", "f32x3": "_f32x3", "bf16": "_bf16", "bf16_exact": "_bf16_exact"}[args.weights]
+    traffic, traffic_ratio, traffic_src, traffic_note = read_traffic("{tag}_pmc_gemm_traffic" + sfx + ".json")
 
     # f32 weights: native f32 MFMA, algorithmic = executed flops.  bf16 weights: each algorithmic product is
     # three bf16 MFMA products (exact activation split), priced against the dense bf16 peak.
     bound = "mfma"
     if args.heuristic == "yolo":
         gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel + conv_sw_kernel (implicit-GEMM convolutions, v_pk_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
-        traffic, traffic_src = None, None
-        for tag in ("r05", "r04", "r03", "r02"):  # tools/collect_yolo_profiles.sh (PMC passes of this command)
-            tp = os.path.join(ROOT, "profiles", f"{tag}_yolo_pmc_conv_traffic.json")
-            if os.path.isfile(tp):
-                try:
-                    traffic, traffic_src = json.load(open(tp))["bytes_per_launch_corrected"], f"profiles/{tag}_yolo_pmc_conv_traffic.json"
-                    break
-                except Exception:
-                    pass
+        traffic, traffic_ratio, traffic_src, traffic_note = read_traffic("{tag}_yolo_pmc_conv_traffic.json")      # tools/collect_yolo_profiles.sh
     elif args.weights == "bf16":
         gemm_kernel, peak, exec_mult = "gemm_bf16w2_wide_kernel / gemm_f32_kernel<WMODE=3> (2 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 2.0
     elif args.weights == "bf16_exact":
@@ -823,18 +930,19 @@ def main():
             "metric": "candidate frames scored/sec (whole node) + sec/video to 8 keyframes, 1h@1fps",
             "value": frames_all / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16": "f32 activations (two round-to-nearest bf16 terms) x bf16 weights, exact products, f32 accumulate",
-                      "bf16_exact": "f32 activations x bf16 weights (exact 3-term split on the bf16 MFMA pipe)",
-                      "f32x3": "f32 held exactly as 3 bf16 terms per operand: every GEMM and vision-attention operand (activations, weights, Q, K, V, softmax "
-                               "probabilities) = three round-to-nearest bf16 terms carrying all 24 significand bits; the 6 partial products with i + j <= 2 "
-                               "(each exact) on v_mfma_f32_32x32x16_bf16, f32 accumulate -- error vs float64 <= the native f32 MFMA kernels' (tests); "
-                               "LayerNorm, softmax statistics, epilogues and head tails plain f32"}[args.weights],
+            "dtype": ("f32 VALU (v_pk_fma_f32 implicit-GEMM convolutions), no MFMA" if args.heuristic == "yolo" else
+                      {"f32": "f32", "bf16": "f32 activations (two round-to-nearest bf16 terms) x bf16 weights, exact products, f32 accumulate",
+                       "bf16_exact": "f32 activations x bf16 weights (exact 3-term split on the bf16 MFMA pipe)",
+                       "f32x3": "f32 held exactly as 3 bf16 terms per operand: every GEMM and vision-attention operand (activations, weights, Q, K, V, softmax "
+                                "probabilities) = three round-to-nearest bf16 terms carrying all 24 significand bits; the 6 partial products with i + j <= 2 "
+                                "(each exact) on v_mfma_f32_32x32x16_bf16, f32 accumulate -- error vs float64 <= the native f32 MFMA kernels' (tests); "
+                                "LayerNorm, softmax statistics, epilogues and head tails plain f32"}[args.weights]),
             "data": "synthetic",
             "config": {
                 "collective_backend": (backend if world > 1 else None), "collective_path": collective_path,
                 "workload": f"{wl_name}: {wl_what}; {det_name}, grid {g}x{g} = "
                             f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
-                "workload_kind": workload, "items_total": n_items_total,
+                "workload_kind": workload, "items_total": n_items_total, "population": population,
                 "sec_per_video": dt / args.steps, "videos_per_rank": args.steps, "searches_in_flight_per_gpu": conc, "lockstep_items_per_batch": max(1, min(args.lockstep, 31)),
                 "lockstep_groups_alternating": max(1, args.pipeline),
                 "mean_search_latency_sec": latency, "single_search_alone_latency_sec": solo_latency,
@@ -842,6 +950,9 @@ def main():
                 # the timed region, per video; host_cores = hardware threads this process may run on (its affinity mask)
                 "host_cpu_sec_per_video": host_cpu / max(args.steps, 1), "host_cpu_busy_cores": host_cpu / dt,
                 "host_cpu_sec_per_video_by_rank": host_cpu_by_rank,
+                # HBM in use on each rank's DEVICE at the end of the timed region (hipMemGetInfo: weights + workspaces + resident videos + torch's
+                # cache; ranks that share a device -- the 1-GPU rehearsal of an N-rank launch -- all report that device's total)
+                "hbm_used_gib_by_rank": hbm_by_rank,
                 "host_cores": _sp.host_threads(), "host_spline_workers": (len(_sp._pool) if _sp._pool is not None else 0),
                 # the per-iteration annotated grid images / frames the reference keeps unconditionally (interface_searcher.py:469-474)
                 # are NOT produced in the timed region (keep_visual_history=False); with them a search costs +2-4 %
@@ -856,18 +967,26 @@ def main():
             },
             "roofline": {
                 "kernel": gemm_kernel, "bound": bound, "achieved": achieved * exec_mult,
-                "peak": peak, "unit": "TFLOP/s", "frac": achieved * exec_mult / peak, "traffic": traffic,
-                "achieved_algorithmic": achieved,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved * exec_mult / peak,
+                # ONE definition per number (review item 2 of round 5).  `achieved` / `frac` price the flops the matrix (or vector) pipe
+                # EXECUTES: `executed_over_algorithmic` hardware products per algorithmic multiply-add (6 in the f32x3 scheme, 2 / 3 in the
+                # bf16-weight modes, 1 for native f32 and the VALU convolutions).  `achieved_algorithmic` / `frac_algorithmic` price the
+                # 2*M*N*K flops of SURVEY 8d against the same peak.  `scheme_ceiling_tflops` = peak / executed_over_algorithmic is the
+                # most algorithmic TFLOP/s this scheme can reach on this pipe; achieved_algorithmic / scheme_ceiling == frac.
+                "frac_definition": "executed flops (achieved = executed_over_algorithmic x achieved_algorithmic) / peak; equals achieved_algorithmic / scheme_ceiling_tflops",
+                "frac_executed": achieved * exec_mult / peak, "frac_algorithmic": achieved / peak,
+                "achieved_algorithmic": achieved, "executed_over_algorithmic": exec_mult, "scheme_ceiling_tflops": peak / exec_mult,
+                "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
                 "traffic_unit": "bytes per launch (L2 fabric side: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "traffic_note": traffic_note,
                 "launches_timed": n_l.value, "timed_every_nth_launch": PROF_STRIDE, "avg_launch_ms": ms.value / max(n_l.value, 1),
                 "avg_launch_gflop": fl.value / max(n_l.value, 1) / 1e9,
                 # every operand read once, the result written once (GEMM: A + W + C + residual + bias rows; conv: input
                 # channels + output channels + weights + fused residual / gate), averaged over the same sampled launches
-                "algorithmic_bytes_per_launch": by.value / max(n_l.value, 1),
-                "traffic_over_algorithmic": (traffic / (by.value / n_l.value)) if traffic and by.value > 0 and n_l.value else None,
+                "algorithmic_bytes_per_launch": alg_bytes_run,
                 "launches_total": n_all.value, "gflop_total": fl_all.value / 1e9,
                 "time_share_of_step": share(fl_all.value, fl.value, ms.value),
+                "gemm_plus_attention_time_share_of_step": share(fl_all.value, fl.value, ms.value) + share(a_fl_all.value, a_fl.value, a_ms.value),
                 "attention_kernel": {"kernel": "attention_x3_kernel (6 x v_mfma_f32_32x32x16_bf16 per step, exact three-term operands)" if args.weights == "f32x3"
                                      else ("attention_split_kernel" if args.weights in ("bf16", "bf16_exact") else "attention_f32_kernel"),
                                      "achieved_algorithmic": (a_fl.value / (a_ms.value * 1e-3) / 1e12) if a_ms.value > 0 else 0.0,
@@ -883,6 +1002,11 @@ def main():
         if world == 1 and not args.no_grid4 and args.heuristic == "owl" and workload == "single" and g != 4:
             g4rec = grid4_record(heuristics[0], shared_store, args.nframes, args.search_nframes)
             out["config"]["grid4"] = g4rec
+        if world == 1 and not args.no_drop_in and args.heuristic == "owl" and workload == "single":
+            try:
+                out["config"]["drop_in"] = drop_in_record(shared_store, args.search_nframes)
+            except Exception as e:                                  # an extra record must never take the headline line down
+                out["config"]["drop_in"] = {"error": repr(e)}
         if (world == 1 and not args.no_other_configs and args.heuristic == "owl" and args.weights == "f32x3" and workload == "single"
                 and args.nframes == N_FRAMES and g == 16 and args.search_nframes == 8):
             out["config"]["other_configs"] = other_configs()
@@ -906,13 +1030,37 @@ def main():
                     cb["measured"] = "sampled (the full search did not finish within its 150 s bound)"
             else:
                 out["cpu_baseline"]["measured"] = "sampled"
+            cb = out["cpu_baseline"]
+            if cb.get("png_write_sec_per_call"):
+                pg = cb["png_write_sec_per_call"]
+                gc_, vc_ = ((cb["full_search"]["grid_calls"], cb["full_search"]["verify_calls"]) if cb.get("full_search")
+                            else (stats_["grid_calls"], stats_["verify_calls"]))
+                fr_ = gc_ * g * g + vc_
+                t_png = gc_ * pg["grid"] + vc_ * pg["verify"]
+                cb["with_png"] = {"sec_per_video": cb["sec_per_video"] + t_png, "value": fr_ / (cb["sec_per_video"] + t_png), "unit": "frames/s",
+                                  "png_sec_per_video": t_png,
+                                  "what": f"cpu_baseline.sec_per_video + {gc_:.0f} grid-image PNG writes ({pg['grid']:.3f} s each, {pg['grid_image']}) + {vc_:.0f} "
+                                          f"verification-frame PNG writes ({pg['verify']:.4f} s each): what the reference's loop costs WITH its per-call "
+                                          "./annotated_image.png; reported beside `value`, not in it (this build writes no such file)"}
             out["config"]["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            di = out["config"].get("drop_in")
+            if di and "error" not in di and cb.get("grid4"):
+                for m_ in ("f32", "f32x3"):
+                    di[m_]["speedup_vs_cpu_baseline_grid4"] = di[m_]["frames_per_s"] / cb["grid4"]["value"]
+                di["cpu_baseline_grid4_sec_per_video"] = cb["grid4"]["sec_per_video"]
             if g4rec and out["cpu_baseline"].get("grid4"):
                 g4rec["speedup_vs_cpu_baseline_lockstep16"] = g4rec["lockstep16_frames_per_s"] / out["cpu_baseline"]["grid4"]["value"]
                 g4rec["speedup_vs_cpu_baseline_solo"] = g4rec["solo_frames_per_s"] / out["cpu_baseline"]["grid4"]["value"]
         print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
+        from tstar_amd import sharding as _sh2
+        if _sh2.COMM_TIMED_OUT:
+            # a helper thread may still sit inside ncclCommInitRank (it cannot be cancelled): the line is out, leave without running
+            # RCCL's / torch's teardown, which could wait for that thread's communicator
+            real_stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         close_comm()
         dist.destroy_process_group()
 

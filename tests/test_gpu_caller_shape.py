@@ -63,6 +63,42 @@ def test_dataset_loop_call_shapes(heuristic, tmp_path):
     assert [float(t) for t in ts] == back[0]["keyframe_timestamps"]
 
 
+def test_environment_selects_the_mode_under_an_unchanged_framework(monkeypatch, tmp_path):
+    """Round 6 (review item 1a): an UNCHANGED ``TStarFramework`` builds the heuristic with ``initialize_heuristic(heuristic_type)`` and
+    no keyword arguments (TStarFramework.py:171-187, 207), so the deployment's choices reach ``OWLInterface`` through the environment:
+    ``TSTAR_WEIGHTS_DTYPE`` / ``TSTAR_MAX_BATCH`` / ``TSTAR_SYNTHETIC_SEED``.  The default-constructed heuristic then runs the bench's
+    headline arithmetic (f32x3) through the stand-in framework's call shapes -- same keyframes as a heuristic built with the keywords;
+    a keyword still wins over the environment."""
+    from tstar_amd.interface_heuristic import initialize_heuristic
+    from tstar_amd.interface_searcher import TStarSearcher
+    for k in ("TSTAR_WEIGHTS_DTYPE", "TSTAR_MAX_BATCH", "TSTAR_SYNTHETIC_SEED"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(FileNotFoundError):
+        initialize_heuristic("owl-vit")                                    # offline, no checkpoint, no seed: as before
+    monkeypatch.setenv("TSTAR_WEIGHTS_DTYPE", "f32x3")
+    monkeypatch.setenv("TSTAR_MAX_BATCH", "16")
+    monkeypatch.setenv("TSTAR_SYNTHETIC_SEED", "0")
+    h_env = initialize_heuristic("owl-vit")                                # the reference's call, no keywords
+    assert h_env.weights_dtype == "f32x3" and h_env.scorer.max_batch == 16 and h_env.weights_source == "synthetic(seed=0)"
+    h_kw = initialize_heuristic("owl-vit", weights_dtype="f32", max_batch=8)   # keywords win; the seed still comes from the environment
+    assert h_kw.weights_dtype == "f32" and h_kw.scorer.max_batch == 8
+    del h_kw
+    args = dict(search_nframes=8, grid_rows=4, grid_cols=4, output_dir=str(tmp_path / "out"), confidence_threshold=0.6, search_budget=0.15)
+    item = {"video_path": "synthetic://n=420,seed=31", "targets": ["couch"], "cues": ["tv", "chair"]}
+    np.random.seed(2025)
+    res_env, _, s_env, _ = CS.run_item(TStarSearcher, h_env, item, args)
+    for k in ("TSTAR_WEIGHTS_DTYPE", "TSTAR_MAX_BATCH", "TSTAR_SYNTHETIC_SEED"):
+        monkeypatch.delenv(k, raising=False)
+    h_ref = initialize_heuristic("owl-vit", synthetic_seed=0, max_batch=16, weights_dtype="f32x3")
+    np.random.seed(2025)
+    res_ref, _, s_ref, _ = CS.run_item(TStarSearcher, h_ref, item, args)
+    assert res_env["keyframe_timestamps"] == res_ref["keyframe_timestamps"]
+    assert s_env.Score_history == s_ref.Score_history
+    monkeypatch.setenv("TSTAR_WEIGHTS_DTYPE", "fp8")
+    with pytest.raises(ValueError, match="TSTAR_WEIGHTS_DTYPE"):
+        initialize_heuristic("owl-vit", synthetic_seed=0)
+
+
 def test_update_top_25_with_window_vs_reference_g3(heuristic, golden_dir):
     """The public ``update_top_25_with_window`` (interface_searcher.py:215-241) on the device score array vs the
     reference's own before/after vectors (chained centres, array ends, a 12-frame video)."""

@@ -805,6 +805,54 @@ def test_speculative_next_grid_equals_the_sequential_loop(monkeypatch, thr, targ
         assert a.device_images_scored == b.device_images_scored + wasted    # the one wasted grid image is counted
 
 
+@pytest.mark.parametrize("kind", ["alters", "replaces"])
+def test_speculation_survives_a_sample_frames_override_that_changes_the_draw(monkeypatch, capsys, kind):
+    """Round 6 (advisor): a wrapper / subclass whose ``sample_frames`` changes the draw -- reorders what the original returned
+    ("alters") or never calls the original and draws from the searcher's generator itself ("replaces") -- used to trip an ``assert``
+    in the speculating loop (and, under ``python -O``, to run the speculated grid with other samples).  Now the speculated forward is
+    dropped for that iteration and the loop goes on with the hook's samples: same result as the plain sequential loop on an
+    identically seeded searcher, the generator left in the same state, nothing left behind in ``_prefetched_secs``."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd.interface_searcher import TStarSearcher
+    from tstar_amd.video import synthetic_video
+    h = OWLInterface(synthetic_seed=0, max_batch=16)
+    store = synthetic_video(500, seed=4)
+
+    def run(sequential):
+        if sequential:
+            monkeypatch.setenv("TSTAR_SOLO_SEQUENTIAL", "1")
+        else:
+            monkeypatch.delenv("TSTAR_SOLO_SEQUENTIAL", raising=False)
+        rng = np.random.RandomState(77)
+        s = TStarSearcher(store, h, ["couch"], ["chair"], search_nframes=4, image_grid_shape=(3, 3), search_budget=0.15,
+                          confidence_threshold=0.9, rng=rng, keep_visual_history=False)
+        orig = s.sample_frames
+        log = []
+        if kind == "alters":
+            def hook(num):
+                secs, frames = orig(num)
+                secs = list(secs)[::-1]
+                log.append(secs)
+                return secs, frames
+        else:
+            def hook(num):
+                secs = sorted(int(v) for v in rng.choice(s.total_frame_num, num, replace=False))
+                log.append(secs)
+                return secs, None
+        s.sample_frames = hook
+        frames, ts = s.search()
+        assert getattr(s, "_prefetched_secs", None) is None
+        return dict(s=s, log=log, ts=list(ts), frames=frames, after=rng.random_sample(3).tolist())
+
+    spec, seq = run(False), run(True)
+    assert spec["log"] == seq["log"] and len(spec["log"]) == spec["s"].iterations >= 3
+    assert spec["ts"] == seq["ts"] and np.array_equal(spec["frames"], seq["frames"])
+    assert spec["after"] == seq["after"]
+    a, b = spec["s"], seq["s"]
+    assert a.Score_history == b.Score_history and a.P_history == b.P_history
+    assert (a.iterations, a.frames_scored, a.detector_calls, a.search_budget) == (b.iterations, b.frames_scored, b.detector_calls, b.search_budget)
+
+
 def test_reference_style_manual_loop_equals_search():
     """Drive the searcher through its PUBLIC methods in the order and with the keywords the reference's own
     ``search()`` body uses (:444-491): ``sample_frames`` -> ``create_image_grid`` -> ``score_image_grids`` (host image,

@@ -189,6 +189,32 @@ def test_bench_gpus2_typed_as_is_spawns_its_ranks():
         assert two["config"]["collective_backend"] == "nccl" and "ncclAllGather" in two["config"]["collective_path"]
 
 
+def test_bench_gpus8_rehearsal_on_one_gpu():
+    """Round 6 (review item 3): the 8-rank launch the driver's SCALE run makes, rehearsed on THIS box -- `python bench.py --gpus 8 ...` typed as
+    is starts 8 ranks through torch.distributed.run; with one GPU visible they share the device and gather over gloo (on an 8-GPU node the same
+    command puts one rank on each GPU and gathers through ncclAllGather).  One line, n_gpus = 8, the 8 gathered rows equal to the 1-rank run's
+    rows for the same 8 items, the per-rank host budget and HBM figures present, and the whole launch -- 8 processes, 8 detector handles,
+    8 x the spline workers -- well inside two minutes."""
+    import time
+    t0 = time.perf_counter()
+    eight = _bench_line([sys.executable, "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "1", "--max-batch", "16", "--no-cpu-baseline",
+                         "--no-grid4", "--no-verify"], _launcher_free_env())
+    wall = time.perf_counter() - t0
+    c = eight["config"]
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "weak" and c["items_total"] == 8 and c["gathered_keyframe_rows"] == 8
+    assert len(c["host_cpu_sec_per_video_by_rank"]) == 8 and all(v > 0 for v in c["host_cpu_sec_per_video_by_rank"])
+    assert len(c["hbm_used_gib_by_rank"]) == 8 and all(1.0 < v < 288.0 for v in c["hbm_used_gib_by_rank"])
+    assert all(len(r) == 8 for r in c["gathered_keyframes"]) and eight["value"] > 0
+    if torch.cuda.device_count() < 8:
+        assert c["collective_backend"] == "gloo" and "gloo" in c["collective_path"]
+    assert wall < 240.0, wall                     # review target 120 s on a warm box; the bound leaves room for a cold page cache
+    print(f"8-rank rehearsal: wall {wall:.1f} s, hbm {max(c['hbm_used_gib_by_rank']):.1f} GiB on the shared device, "
+          f"host cpu/video by rank {[round(v, 2) for v in c['host_cpu_sec_per_video_by_rank']]}")
+    one = _bench_line([sys.executable, "bench.py", "--workload", "haystack", "--steps", "8", "--warmup", "1", "--max-batch", "16", "--no-cpu-baseline",
+                       "--no-grid4", "--no-verify"], _launcher_free_env())
+    assert one["config"]["gathered_keyframes"] == c["gathered_keyframes"]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: real RCCL between two ranks")
 def test_bench_gpus2_over_rccl():
     """On a multi-GPU box: the plain `python bench.py --gpus 2` command, one rank per GPU, the keyframe rows collected by
@@ -226,10 +252,30 @@ def test_bench_line_contract():
     # executed = 6 x algorithmic
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0.4 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and abs(r["achieved"] - 6.0 * r["achieved_algorithmic"]) < 1e-6 * r["achieved"]
+    # round 6: one definition per number -- executed vs algorithmic fraction, the scheme's ceiling, and a traffic ratio only across ONE
+    # launch population (this 3-step run is not the 16-step population of the PMC collection: null, with the reason)
+    assert r["frac_executed"] == r["frac"] and r["executed_over_algorithmic"] == 6.0 and abs(r["scheme_ceiling_tflops"] - 2500.0 / 6) < 1e-9
+    assert abs(r["frac_algorithmic"] - r["achieved_algorithmic"] / r["peak"]) < 1e-12 and abs(r["frac_algorithmic"] * 6.0 - r["frac"]) < 1e-9
+    assert abs(r["achieved_algorithmic"] / r["scheme_ceiling_tflops"] - r["frac"]) < 1e-9 and "executed" in r["frac_definition"]
+    assert r["traffic"] is None and r["traffic_over_algorithmic"] is None and ("population" in r["traffic_note"] or "PMC" in r["traffic_note"])
+    assert c["population"]["steps"] == 3 and c["population"]["weights"] == "f32x3" and c["population"]["lockstep"] == 8
+    assert abs(r["gemm_plus_attention_time_share_of_step"] - r["time_share_of_step"] - r["attention_kernel"]["time_share_of_step"]) < 1e-12
     assert r["launches_total"] >= r["launches_timed"] * (r["timed_every_nth_launch"] - 1) and r["launches_timed"] > 0
     assert 0.5 < r["time_share_of_step"] + r["attention_kernel"]["time_share_of_step"] < 1.0
     assert "attention_x3" in r["attention_kernel"]["kernel"]
     assert b["kind"] == "port" and b["cores"] >= 1 and 1 < b["value"] < d["value"] and b["unit"] == "frames/s" and b["sample"]
+    # round 6: the reference's per-call debug PNG (interface_heuristic.py:248-256) reported separately, never inside `value`
+    png = b["png_write_sec_per_call"]
+    assert png["grid"] > png["verify"] > 0 and png["grid_image"] == "3200x1520" and png["verify_image"] == "600x285"
+    assert b["with_png"]["sec_per_video"] > b["sec_per_video"] and b["with_png"]["value"] < b["value"] and "decord" in b["decode_note"]
+    # round 6: what an UNCHANGED TStarFramework gets (default-constructed heuristic, one 4x4 search alone, history ON), both modes
+    di = c["drop_in"]
+    assert "error" not in di, di
+    for m in ("f32", "f32x3"):
+        assert 0.05 < di[m]["sec_per_video"] < 5 and di[m]["grid_calls"] == 63 and di[m]["history_entries"] >= 63 and len(di[m]["keyframes"]) == 8
+        assert di[m]["max_batch"] == 32
+    assert di["f32"]["env"]["TSTAR_WEIGHTS_DTYPE"] is None and di["f32x3"]["env"]["TSTAR_WEIGHTS_DTYPE"] == "f32x3"
+    assert di["sec_per_video"] == di["f32x3"]["sec_per_video"] < di["f32"]["sec_per_video"]
     # round 4: the host budget of a rank (what predicts the 8-rank curve), the visual-history statement, and the other BASELINE
     # configs observed through the same line
     assert c["visual_history"] is False and c["host_cores"] >= 1 and 0 < c["host_cpu_sec_per_video"] < 60 and c["host_cpu_busy_cores"] > 0
@@ -240,6 +286,7 @@ def test_bench_line_contract():
         assert rec["keyframes_verified"] is True and rec["value"] > 1000 and 0 < rec["roofline"]["frac"] < 1, (name, rec)
     y = [v for k, v in oc.items() if "configs[3]" in k][0]
     assert y["roofline"]["bound"] == "valu" and "configs[3]" in y["workload"]
+    assert "VALU" in y["dtype"] and "no MFMA" in y["dtype"] and "bf16" not in y["dtype"] and y["roofline"]["executed_over_algorithmic"] == 1.0
     c5 = [v for k, v in oc.items() if "configs[4]" in k][0]
     assert "14400-frame" in c5["workload"] and "search_nframes=32" in c5["workload"] and "bf16" in c5["dtype"]
     nat = [v for k, v in oc.items() if "native f32" in k][0]

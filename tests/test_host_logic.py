@@ -42,6 +42,23 @@ def test_no_cpu_fallback_without_gpu():
         OWLInterface(device="cpu", synthetic_seed=0)
 
 
+def test_environment_knobs_are_validated_before_anything_is_loaded(monkeypatch):
+    """TSTAR_WEIGHTS_DTYPE / TSTAR_MAX_BATCH / TSTAR_SYNTHETIC_SEED stand in for the keyword arguments an unchanged TStarFramework
+    cannot pass (TStarFramework.py:171-187, 207); a bad value is reported by name, before weights are touched."""
+    from tstar_amd.interface_heuristic import OWLInterface, _env_int
+    monkeypatch.setenv("TSTAR_WEIGHTS_DTYPE", "fp8")
+    with pytest.raises(ValueError, match="TSTAR_WEIGHTS_DTYPE"):
+        OWLInterface()
+    monkeypatch.setenv("TSTAR_WEIGHTS_DTYPE", "f32x3")
+    monkeypatch.setenv("TSTAR_MAX_BATCH", "lots")
+    with pytest.raises(ValueError, match="TSTAR_MAX_BATCH must be an integer"):
+        OWLInterface()
+    monkeypatch.setenv("TSTAR_MAX_BATCH", "")
+    assert _env_int("TSTAR_MAX_BATCH", 32) == 32
+    monkeypatch.setenv("TSTAR_MAX_BATCH", "48")
+    assert _env_int("TSTAR_MAX_BATCH", 32) == 48
+
+
 def test_heuristic_factory_names():
     """initialize_heuristic keeps the reference's type names (TStarFramework.py:171-187): 'owl-vit' and 'yolo-World' are
     built (the latter needs weights: nothing can be downloaded), unknown names raise NotImplementedError like the
@@ -364,6 +381,42 @@ def test_open_video_through_a_decord_like_reader(monkeypatch):
     want = [int(s * 29.97) % 251 for s in range(10)]
     assert [int(st.frames[s, 0, 0, 0]) for s in range(10)] == want
     assert st.shape == (10, 6, 8, 3)
+
+
+def test_comm_create_watchdog(monkeypatch):
+    """Round 6 (review item 3): ``tstar_comm_create`` = ncclCommInitRank, a collective that can HANG (a peer that never arrives) instead
+    of failing.  The watchdog runs it on a helper thread: a call that returns is passed through (handle / error text read on the thread
+    that made the call), one that does not return within TSTAR_COMM_TIMEOUT_S is abandoned and reported, so that the gather falls back
+    to torch.distributed instead of eating the job's time limit."""
+    import threading
+    import time
+    from tstar_amd import _lib, sharding as SH
+    lib = _lib.load()
+    monkeypatch.setenv("TSTAR_COMM_TIMEOUT_S", "0.2")
+    assert SH.comm_timeout_s() == 1.0                                     # floor of one second
+    monkeypatch.setenv("TSTAR_COMM_TIMEOUT_S", "soon")
+    assert SH.comm_timeout_s() == 90.0
+    seen = {}
+
+    def ok(hp, uid, world, rank):
+        seen["thread"] = threading.current_thread().name
+        seen["args"] = (bytes(uid), world, rank)
+        return 0
+
+    h, note = SH._create_with_watchdog(lib, b"x" * 128, 8, 3, 5.0, create=ok)
+    assert h is not None and note == "" and seen["thread"] == "tstar-comm-create" and seen["args"] == (b"x" * 128, 8, 3)
+    h, note = SH._create_with_watchdog(lib, b"x" * 128, 8, 3, 5.0, create=lambda *a: 2)
+    assert h is None and note                                              # an error code: no handle, a reason
+    release = threading.Event()
+    monkeypatch.setattr(SH, "COMM_TIMED_OUT", False)
+    t0 = time.perf_counter()
+    h, note = SH._create_with_watchdog(lib, b"x" * 128, 8, 3, 0.3, create=lambda *a: (release.wait(20), 0)[1])
+    assert h is None and "did not return within" in note and "8 ranks" in note and SH.COMM_TIMED_OUT is True
+    assert time.perf_counter() - t0 < 5.0                                  # the caller got its thread back
+    release.set()
+    # the real entry point with a bad argument comes back through the same path with the library's own message
+    h, note = SH._create_with_watchdog(lib, b"x" * 128, 2, 5, 5.0)
+    assert h is None and "rank must be in 0..world-1" in note
 
 
 def test_shard_interleave_property():

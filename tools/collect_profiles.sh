@@ -51,13 +51,13 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_IN
     # --steps 16: the default line's own launch population (two lock-step groups of 8), so that bytes per launch compare like with like;
     # --no-grid4 --no-verify: every GEMM dispatch of the run is one of the timed steps' (plus the text tower's 48 tiny ones),
     # so the per-launch averages are over the same population as the bench line's avg_launch_gflop
-    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 16 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify --no-other-configs > /dev/null 2> "$OUT/rocprof_$N.err"
+    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof_$N -o pmc -- $PY --steps 16 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify --no-other-configs --no-drop-in > "$OUT/pmc_pass_$N.json" 2> "$OUT/rocprof_$N.err"
 done
 F=$(find /tmp/prof_FETCH_SIZE -name '*.db' | head -1)
 W=$(find /tmp/prof_WRITE_SIZE -name '*.db' | head -1)
 M=$(find /tmp/prof_SQ_VALU_MFMA_BUSY_CYCLES_GRBM_GUI_ACTIVE -name '*.db' | head -1)
 M2=$(find /tmp/prof_SQ_INSTS_VALU_MFMA_MOPS_F32_SQ_BUSY_CYCLES -name '*.db' | head -1)
-python $ROOT/tools/rocpd_traffic.py "$F" "$W" "gemm_f32|gemm_bf16w2_wide" > "$OUT/${TAG}_pmc_gemm_traffic_f32x3.json"      # the bench default is the f32x3 mode since round 5
+python $ROOT/tools/rocpd_traffic.py "$F" "$W" "gemm_f32|gemm_bf16w2_wide" "" "$OUT/pmc_pass_FETCH_SIZE.json" > "$OUT/${TAG}_pmc_gemm_traffic_f32x3.json"      # the bench default is the f32x3 mode since round 5
 python $ROOT/tools/rocpd_pmc.py "$F" "$W" > "$OUT/${TAG}_pmc_fetch_write_by_kernel.md"
 python $ROOT/tools/rocpd_pmc.py "$M" "$M2" > "$OUT/${TAG}_pmc_mfma_by_kernel.md"
 python $ROOT/tools/rocpd_mfma.py "$M" > "$OUT/${TAG}_pmc_mfma_utilisation.md"

@@ -25,13 +25,14 @@ rm -rf /tmp/prof_yolo3
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d /tmp/prof_yolo3 -o pmc -- python $ROOT/tools/yolo_forward_probe.py 76 > /dev/null 2> "$OUT/rocprof_yolo_pmc.err"
 python $ROOT/tools/rocpd_pmc.py "$(find /tmp/prof_yolo3 -name '*.db' | head -1)" > "$OUT/${TAG}_yolo_pmc_valu_by_kernel.md"
 # fabric-side traffic of the convolutions, on the bench command itself (same launch population as its roofline.achieved)
-YB="$PY --heuristic yolo --steps 24 --warmup 0 --no-cpu-baseline --no-verify --no-other-configs"
+# --steps 48: the default YOLO line's own launch population (two lock-step groups of 24); bench.py quotes the figure only for a run of the same population
+YB="$PY --heuristic yolo --steps 48 --warmup 0 --no-cpu-baseline --no-verify --no-other-configs"
 rm -rf /tmp/prof_yolo4
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_yolo4 -o pmc -- $YB > /dev/null 2>> "$OUT/rocprof_yolo_pmc.err"
+timeout 700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_yolo4 -o pmc -- $YB > "$OUT/pmc_pass_yolo_FETCH_SIZE.json" 2>> "$OUT/rocprof_yolo_pmc.err"
 rm -rf /tmp/prof_yolo5
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_yolo5 -o pmc -- $YB > /dev/null 2>> "$OUT/rocprof_yolo_pmc.err"
+timeout 700 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_yolo5 -o pmc -- $YB > /dev/null 2>> "$OUT/rocprof_yolo_pmc.err"
 python $ROOT/tools/rocpd_traffic.py "$(find /tmp/prof_yolo4 -name '*.db' | head -1)" "$(find /tmp/prof_yolo5 -name '*.db' | head -1)" "conv_valu|conv_sw|conv_halo" \
-    "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --heuristic yolo --steps 24 --warmup 0 --no-cpu-baseline --no-verify --no-other-configs (tools/collect_yolo_profiles.sh)" > "$OUT/${TAG}_yolo_pmc_conv_traffic.json"
+    "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --heuristic yolo --steps 48 --warmup 0 --no-cpu-baseline --no-verify --no-other-configs (tools/collect_yolo_profiles.sh)" "$OUT/pmc_pass_yolo_FETCH_SIZE.json" > "$OUT/${TAG}_yolo_pmc_conv_traffic.json"
 cp "$OUT/${TAG}_yolo_pmc_conv_traffic.json" "$ROOT/profiles/${TAG}_yolo_pmc_conv_traffic.json"
 $PY --heuristic yolo --steps 48 --warmup 1 > "$OUT/${TAG}_bench_yolo.json" 2>> "$OUT/bench_yolo.err"
 ls -la "$OUT" | grep yolo

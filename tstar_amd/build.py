@@ -79,18 +79,30 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # or one where it does not compile, gets a warning, not a failed build.  Rebuilt when the source or the flags change.
     stamp = FIT_LIB + ".flags"
     flags_now = " ".join(FIT_FLAGS)
-    stale_fit = (force or not os.path.exists(FIT_LIB) or os.path.getmtime(FIT_LIB) < os.path.getmtime(FIT_SRC)
-                 or not os.path.exists(stamp) or open(stamp).read() != flags_now)
+    flags_built = None
+    if os.path.exists(stamp):
+        with open(stamp) as f:
+            flags_built = f.read()
+    stale_fit = (force or not os.path.exists(FIT_LIB) or os.path.getmtime(FIT_LIB) < os.path.getmtime(FIT_SRC) or flags_built != flags_now)
     if stale_fit:
         gxx = os.environ.get("CXX") or shutil.which("g++")
         try:
             if not gxx:
                 raise RuntimeError("g++ not found (set CXX)")
-            run([gxx] + FIT_FLAGS + [FIT_SRC, "-o", FIT_LIB])
+            run([gxx] + FIT_FLAGS + [FIT_SRC, "-o", FIT_LIB + ".tmp"])
+            os.replace(FIT_LIB + ".tmp", FIT_LIB)
             with open(stamp, "w") as f:
                 f.write(flags_now)
         except Exception as e:                         # noqa: BLE001 -- any failure here only costs the fast fit
-            print(f"[build] WARNING: libtstar_fitpack.so not built ({str(e).splitlines()[0]}); the spline fit falls back to scipy", file=sys.stderr)
+            # a library OLDER than its source (or built with other flags) must not be loaded in its place: new Python against an old
+            # binary may lack entry points (tstar_curfit_pairing) or differ in bits.  Without the file the workers take scipy's own fit.
+            for stale in (FIT_LIB, FIT_LIB + ".tmp", stamp):
+                try:
+                    os.remove(stale)
+                except OSError:
+                    pass
+            print(f"[build] WARNING: libtstar_fitpack.so not built ({str(e).splitlines()[0]}); the stale library was removed, "
+                  "the spline fit falls back to scipy", file=sys.stderr)
     return LIB
 
 

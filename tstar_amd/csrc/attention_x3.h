@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(const float* __res
 
     f32x4 rk[2], rv[2];
     auto gload = [&](int kb) __attribute__((always_inline)) {
-        const int so = kb * (KB * 4) * D3;                                  // past the last tile: zeros (never staged)
+        const int so = (kb < nkb ? kb : nkb) * (KB * 4) * D3;               // past the last tile: zeros (never staged); clamped so that the look-ahead
+                                                                            // tiles nkb + 1, nkb + 2 cannot overflow the int offset near the 2-GiB row limit
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rsrc, kvo[i], so, 0));
@@ -543,9 +544,12 @@ __global__ __launch_bounds__(256) void kv_planes_kernel(const float* __restrict_
 // it is 7 % faster (159.7 vs 148.8 TFLOP/s, profiles/r05_attention_x3_planes_dma_lab.log) -- about 1 % of a step, less than what
 // writing the tiles from the qkv GEMM's epilogue would cost -- so the library does not use it.
 inline int attention_x3_launch(const float* qkv, float* out, int B, int T, int heads, hipStream_t s, const char* planes = nullptr) {
-    static bool attr[2] = {false, false};
     const int qtiles = (T + 127) / 128;
 #ifdef TSTAR_ATTN_X3_LAB
+    // the lab harness is one device, one host thread: a process-wide flag is enough there.  The LIBRARY raises the dynamic-LDS
+    // limit through ensure_dyn_lds (keyed on kernel AND device, mutex-protected: the attribute applies to the current device only)
+    // before it calls this launcher -- csrc/attention_x3.hip.
+    static bool attr[2] = {false, false};
     if (planes) {
         if (!attr[1]) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ax3::attention_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ax3::LDS_BYTES);
@@ -555,13 +559,13 @@ inline int attention_x3_launch(const float* qkv, float* out, int B, int T, int h
         hipLaunchKernelGGL(ax3::attention_x3_kernel<true>, dim3(B * heads * qtiles), dim3(256), ax3::LDS_BYTES, s, qkv, planes, out, T, heads, qtiles);
         return (int)hipGetLastError();
     }
-#endif
-    if (planes) return (int)hipErrorInvalidValue;
     if (!attr[0]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ax3::attention_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ax3::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr[0] = true;
     }
+#endif
+    if (planes) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(ax3::attention_x3_kernel<false>, dim3(B * heads * qtiles), dim3(256), ax3::LDS_BYTES, s, qkv, planes, out, T, heads, qtiles);
     return (int)hipGetLastError();
 }

@@ -52,6 +52,16 @@ class Detections:
         return int(self.xyxy.shape[0])
 
 
+def _env_int(name: str, default):
+    v = os.environ.get(name)
+    if v is None or v.strip() == "":
+        return default
+    try:
+        return int(v)
+    except ValueError:
+        raise ValueError(f"{name} must be an integer, not {v!r}") from None
+
+
 class HeuristicInterface:
     def __init__(self, heuristic_type: str = "owl-vit", **kwargs):
         """Base of the detector plug-ins (empty in the reference too, interface_heuristic.py:28-37)."""
@@ -59,9 +69,15 @@ class HeuristicInterface:
 
 class OWLInterface(HeuristicInterface):
     def __init__(self, model_name_or_path: str = "google/owlvit-base-patch32", device: str = "cuda",
-                 max_batch: int = 32, synthetic_seed: Optional[int] = None, state_dict: Optional[Dict] = None,
-                 weights_dtype: str = "f32", allow_standin_tokenizer: Optional[bool] = None):
+                 max_batch: Optional[int] = None, synthetic_seed: Optional[int] = None, state_dict: Optional[Dict] = None,
+                 weights_dtype: Optional[str] = None, allow_standin_tokenizer: Optional[bool] = None):
         """``device`` must be a HIP device (default "cuda" as in the reference, :201).
+
+        Under an UNCHANGED ``TStarFramework`` the heuristic is built by ``initialize_heuristic(heuristic_type)`` without keyword
+        arguments (TStarFramework.py:171-187, 207), so the three arguments a deployment chooses can also come from the environment
+        -- read only when the keyword is not given: ``TSTAR_WEIGHTS_DTYPE`` (``weights_dtype``; default "f32"),
+        ``TSTAR_MAX_BATCH`` (``max_batch``; default 32) and ``TSTAR_SYNTHETIC_SEED`` (``synthetic_seed``; unset = no synthetic
+        weights: a missing checkpoint raises).
 
         Weights: ``state_dict`` (HF names) if given; else a local safetensors checkpoint of
         ``model_name_or_path`` if one exists on disk; else, only when ``synthetic_seed`` is not None,
@@ -81,6 +97,14 @@ class OWLInterface(HeuristicInterface):
         from .owl import OwlScorer
         if not str(device).startswith("cuda"):
             raise ValueError("tstar_amd.OWLInterface runs on the GPU only (device='cuda[:i]'); it has no CPU path")
+        if weights_dtype is None:
+            weights_dtype = os.environ.get("TSTAR_WEIGHTS_DTYPE") or "f32"
+        if weights_dtype not in ("f32", "bf16", "bf16_exact", "f32x3"):
+            raise ValueError(f"weights_dtype (or TSTAR_WEIGHTS_DTYPE) must be 'f32', 'bf16', 'bf16_exact' or 'f32x3', not {weights_dtype!r}")
+        if max_batch is None:
+            max_batch = _env_int("TSTAR_MAX_BATCH", 32)
+        if synthetic_seed is None and state_dict is None:
+            synthetic_seed = _env_int("TSTAR_SYNTHETIC_SEED", None)
         dev = torch.device(device)
         if dev.index is not None:
             torch.cuda.set_device(dev.index)
@@ -101,8 +125,6 @@ class OWLInterface(HeuristicInterface):
         if allow_standin_tokenizer is None:
             allow_standin_tokenizer = self.weights_source.startswith("synthetic(")
         self.allow_standin_tokenizer = bool(allow_standin_tokenizer)
-        if weights_dtype not in ("f32", "bf16", "bf16_exact", "f32x3"):
-            raise ValueError("weights_dtype must be 'f32', 'bf16', 'bf16_exact' or 'f32x3'")
         if weights_dtype in ("bf16", "bf16_exact"):
             state_dict = W.round_weights_to_bf16(state_dict)
         self.weights_dtype = weights_dtype

@@ -33,6 +33,7 @@ from .video import FrameStore, open_video
 
 CELL_W, CELL_H = 200, 95            # create_image_grid's hard-coded cell size (:186)
 VERIFY_W, VERIFY_H = 200 * 3, 95 * 3  # verify_and_remove_target's resize (:403)
+SAMPLER_WARNING = "Warning: Not enough non-zero entries, adjusting probability distribution."      # (:350)
 
 
 class _DeviceState:
@@ -454,11 +455,17 @@ class TStarSearcher:
         secs = self._sample_secs(num_samples)
         return secs, _ResizedFrames(self, secs, CELL_W * 4, CELL_H * 4)
 
-    def _sample_secs(self, num_samples: int) -> List[int]:
+    def _sample_secs(self, num_samples: int, _warned: Optional[list] = None) -> List[int]:
+        """The draw of ``sample_frames``.  ``_warned`` (lockstep's speculative draw): a list that receives the fallback-branch
+        flag INSTEAD of the warning being printed -- the warning is printed when, and only if, the draw is adopted."""
         pre = getattr(self, "_prefetched_secs", None)
         if pre is not None:                     # drawn ahead by lockstep._Group.speculate() from the same generator state
             self._prefetched_secs = None
-            return pre
+            secs, post_state, warned = pre
+            (self._rng if self._rng is not None else np.random).set_state(post_state)    # where that draw left the generator
+            if warned:
+                print(SAMPLER_WARNING)
+            return secs
         if num_samples > self.total_frame_num:
             num_samples = self.total_frame_num
         if not self.Score_history:
@@ -468,7 +475,10 @@ class TStarSearcher:
                 secs = np.append(secs, self.total_frame_num - 1)
         else:
             if self._state.sampler_prep(num_samples, num_samples / self.total_frame_num):
-                print("Warning: Not enough non-zero entries, adjusting probability distribution.")
+                if _warned is not None:
+                    _warned.append(True)
+                else:
+                    print(SAMPLER_WARNING)
             secs = self._choice(num_samples)
         return [int(s) for s in secs]
 

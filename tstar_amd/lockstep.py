@@ -26,7 +26,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 from . import spline_pool
-from .interface_searcher import TStarSearcher
+from .interface_searcher import SAMPLER_WARNING, TStarSearcher
 
 MAX_GROUP = 63          # TSTAR_OWL_MAX_SETS - 1 query-set slots (include/tstar_hip.h); slot 0 stays the heuristic's own
 
@@ -92,24 +92,53 @@ class _Group:
         ``speculate()`` queued exactly this iteration behind the previous verification batch, nothing but taking it over."""
         torch = self.torch
         if self.spec is not None:
-            items, secs_l, grids, res, ev, _ = self.spec
+            items, secs_l, grids, res, ev, states, warned = self.spec
+            if items != self.act:
+                raise AssertionError("stale speculation: end() must have discarded it")
             self.spec = None
-            if items == self.act:                 # every speculated item is still searching (and no other is): the work is already queued
-                if self.solo:                     # the hook sees the draw now, at the reference's place
-                    for s, secs in zip(items, secs_l):
-                        s._prefetched_secs = list(secs)
-                        got = [int(v) for v in s.sample_frames(self.n)[0]]
-                        assert got == secs, "a sample_frames override changed the speculated draw"
+            # every speculated item is still searching (and no other is): the work is already queued
+            if not self.solo:
+                for w in warned:
+                    if w:
+                        print(SAMPLER_WARNING)        # the draw is adopted: the warning belongs to an executed iteration
                 self.secs_l, self.grids, self.res, self.ev_grid = secs_l, grids, res, ev
                 return
-            raise AssertionError("stale speculation: end() must have discarded it")
-        secs_l, grids = [], []
+            # solo: the public hook sees the draw now, at the reference's place.  The generator is put back to where it was
+            # BEFORE the speculative draw and the draw is handed to ``_sample_secs`` together with the state after it: a hook that
+            # goes through the original method gets the speculated draw and leaves the generator where the sequential loop would;
+            # a hook that replaces the method draws from the state the sequential loop would have given it.
+            s, secs = items[0], secs_l[0]
+            rng = s._rng if s._rng is not None else np.random
+            post = rng.get_state()
+            rng.set_state(states[0])
+            s._prefetched_secs = (list(secs), post, warned[0])
+            try:
+                with torch.cuda.stream(self.side):    # (a replacing hook may run state kernels of its own)
+                    got = [int(v) for v in s.sample_frames(self.n)[0]]
+            finally:
+                s._prefetched_secs = None             # never left behind for an unrelated later draw
+            if got == secs:
+                self.secs_l, self.grids, self.res, self.ev_grid = secs_l, grids, res, ev
+                return
+            # an override changed (or replaced) the draw: the iteration runs on ITS samples, as in the sequential loop; the
+            # speculated forward is dropped (the image did go through the detector).  The budget was already charged.
+            s.device_images_scored += 1
+            cb = getattr(self.h, "_speculation_dropped", None)
+            if cb is not None:
+                cb(res)
+            self._score_grids([got])
+            return
+        secs_l = []
         with torch.cuda.stream(self.side):
             for s in self.act:
                 secs_l.append(self._draw(s))
                 s.search_budget -= self.n
-        for s, secs in zip(self.act, secs_l):
-            grids.append(s._device_grid(secs))
+        self._score_grids(secs_l)
+
+    def _score_grids(self, secs_l):
+        """Grid images of the active items' samples and their forward, on the detector stream."""
+        torch = self.torch
+        grids = [s._device_grid(secs) for s, secs in zip(self.act, secs_l)]
         self.secs_l, self.grids = secs_l, grids
         self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(self.act))
         self.ev_grid = torch.cuda.Event()
@@ -129,20 +158,22 @@ class _Group:
         if not items or len(items) != len(self.act):
             return                                # an item stops on its budget after this iteration: begin() draws for the rest
         states = [(s._rng if s._rng is not None else np.random).get_state() for s in items]
-        secs_l, grids = [], []
+        secs_l, grids, warned = [], [], []
         with torch.cuda.stream(self.side):
             for s in items:
-                secs_l.append(s._sample_secs(self.n))          # NOT the public hook: a discarded draw must stay invisible
+                w = []
+                secs_l.append(s._sample_secs(self.n, _warned=w))   # NOT the public hook, and no warning printed: a discarded draw must stay invisible
+                warned.append(bool(w and w[0]))
                 s.search_budget -= self.n
         for s, secs in zip(items, secs_l):
             grids.append(s._device_grid(secs))
         res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(items))
         ev = torch.cuda.Event()
         ev.record(self.main)
-        self.spec = (items, secs_l, grids, res, ev, states)
+        self.spec = (items, secs_l, grids, res, ev, states, warned)
 
     def _drop_speculation(self):
-        items, _, _, res, _, states = self.spec
+        items, _, _, res, _, states, _ = self.spec
         self.spec = None
         for s, st in zip(items, states):
             (s._rng if s._rng is not None else np.random).set_state(st)

@@ -12,11 +12,61 @@ latency-bound.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import sys
+import threading
 from typing import Callable, List, Sequence
 
 _COMM = None            # this process' tstar_comm handle (RCCL communicator created through the C ABI), or False = unavailable
+_COMM_NOTE = ""         # why the library's communicator is not in use (reported in LAST_GATHER_PATH)
+COMM_TIMED_OUT = False  # the watchdog gave up on tstar_comm_create: a thread of this process may still sit inside ncclCommInitRank
 LAST_GATHER_PATH = None  # which way the last gather_keyframes() went (bench.py reports it as config.collective_path)
+
+
+def comm_timeout_s() -> float:
+    """Seconds the watchdog gives ``tstar_comm_create`` (ncclCommInitRank, a collective that can HANG rather than fail when a peer never
+    arrives or the fabric bootstrap stalls) before the gather falls back to torch.distributed.  TSTAR_COMM_TIMEOUT_S, default 90."""
+    try:
+        return max(1.0, float(os.environ.get("TSTAR_COMM_TIMEOUT_S", "90")))
+    except ValueError:
+        return 90.0
+
+
+def _create_with_watchdog(lib, uid: bytes, world: int, rank: int, timeout_s: float, create=None):
+    """``tstar_comm_create`` on a helper thread (ctypes drops the GIL for the call) -> (handle or None, note).  On a timeout the thread is
+    left behind as a daemon -- ncclCommInitRank cannot be cancelled -- and the caller must not touch the communicator it may still produce."""
+    global COMM_TIMED_OUT
+    h = C.c_void_p()
+    box = {}
+    dev = None
+    try:
+        import torch
+        dev = torch.cuda.current_device()
+    except Exception:
+        pass
+
+    def work():
+        try:
+            if dev is not None:
+                import torch
+                torch.cuda.set_device(dev)               # the current device is per thread: ncclCommInitRank binds to it
+            box["rc"] = (create or lib.tstar_comm_create)(C.byref(h), uid, world, rank)
+            if box["rc"] != 0:
+                box["err"] = lib.tstar_last_error().decode()      # the library's error text is per thread: read it on this one
+        except BaseException as e:                        # noqa: BLE001 -- reported to the caller's thread
+            box["exc"] = e
+
+    t = threading.Thread(target=work, name="tstar-comm-create", daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        COMM_TIMED_OUT = True
+        return None, f"tstar_comm_create (ncclCommInitRank, {world} ranks) did not return within {timeout_s:.0f} s: watchdog fallback"
+    if "exc" in box:
+        return None, f"tstar_comm_create raised {box['exc']!r}"
+    if box.get("rc") != 0:
+        return None, box.get("err") or f"tstar_comm_create failed (code {box.get('rc')})"
+    return h, ""
 
 
 def _tstar_comm(world: int, rank: int):
@@ -24,7 +74,7 @@ def _tstar_comm(world: int, rank: int):
     initialised torch.distributed group: rank 0 draws the unique id, the id is broadcast, every rank joins.  Returns
     the handle, or None when RCCL could not be bound (the caller then gathers through torch.distributed, which is
     RCCL as well)."""
-    global _COMM
+    global _COMM, _COMM_NOTE
     if _COMM is not None:
         return _COMM or None
     import torch
@@ -35,10 +85,12 @@ def _tstar_comm(world: int, rank: int):
     # cannot load the library must be known before any rank enters it (the others would block inside it forever)
     have = 1 if lib.tstar_comm_available() == 0 else 0
     if not have:
-        print(f"tstar_amd[rank {rank}]: {lib.tstar_last_error().decode()}; gathering through torch.distributed", file=sys.stderr)
+        _COMM_NOTE = lib.tstar_last_error().decode()
+        print(f"tstar_amd[rank {rank}]: {_COMM_NOTE}; gathering through torch.distributed", file=sys.stderr)
     pre = torch.tensor([have], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(pre, op=dist.ReduceOp.MIN)
     if int(pre.item()) != 1:
+        _COMM_NOTE = _COMM_NOTE or "RCCL is not loadable on another rank"
         _COMM = False
         return None
     idbuf = C.create_string_buffer(128)
@@ -49,17 +101,21 @@ def _tstar_comm(world: int, rank: int):
             print(f"tstar_amd: {lib.tstar_last_error().decode()}; gathering through torch.distributed", file=sys.stderr)
     dist.broadcast_object_list(box, src=0)
     if box[0] is None:
+        _COMM_NOTE = "ncclGetUniqueId failed on rank 0"
         _COMM = False
         return None
-    h = C.c_void_p()
-    ok = lib.tstar_comm_create(C.byref(h), box[0], world, rank) == 0
+    # ncclCommInitRank under a watchdog: an ERROR comes back as a code, a HANG (a peer that never arrives, a stalled bootstrap) would
+    # otherwise eat the whole job's time limit.  Every rank then agrees (MIN) on whether the communicator is up.
+    h, note = _create_with_watchdog(lib, box[0], world, rank, comm_timeout_s())
+    ok = h is not None
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) != 1:
         if ok:
             lib.tstar_comm_destroy(h)
-        elif rank == 0:
-            print(f"tstar_amd: {lib.tstar_last_error().decode()}; gathering through torch.distributed", file=sys.stderr)
+            note = "tstar_comm_create failed or timed out on another rank"
+        _COMM_NOTE = note
+        print(f"tstar_amd[rank {rank}]: {note}; gathering through torch.distributed", file=sys.stderr)
         _COMM = False
         return None
     _COMM = h
@@ -68,11 +124,12 @@ def _tstar_comm(world: int, rank: int):
 
 def close_comm():
     """Destroy the library's communicator (before torch.distributed.destroy_process_group)."""
-    global _COMM
+    global _COMM, _COMM_NOTE
     if _COMM:
         from . import _lib
         _lib.load().tstar_comm_destroy(_COMM)
     _COMM = None
+    _COMM_NOTE = ""
 
 
 
@@ -128,7 +185,7 @@ def gather_keyframes(local_rows: Sequence[Sequence[int]], world: int, pad_to: in
         out = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(out, buf)
         LAST_GATHER_PATH = (f"torch.distributed.all_gather over {dist.get_backend()} ({world} ranks)"
-                            + ("; the library's RCCL communicator was unavailable" if on_gpu else ""))
+                            + (f"; the library's RCCL communicator was unavailable ({_COMM_NOTE})" if on_gpu else ""))
     res: List[List[int]] = []
     for t in out:
         flat_r = t.cpu().numpy()
