@@ -136,6 +136,19 @@ int tstar_owl_get_query_embeds(tstar_owl* h, int query_set, float* h_out, int Q,
 int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
                     const int32_t* h_image_query_set, float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
                     uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits, float* d_boxes_cxcywh, void* stream);
+/* Round 6 (an added entry point; tstar_abi_version() stays 3).  The same call on workspace `lane` (0 .. TSTAR_OWL_LANES - 1).  tstar_owl_score is lane 0, the handle's own workspace of
+ * max_batch images.  Lane 1 is a second, SMALL workspace (forward chunks of min(max_batch, TSTAR_OWL_AUX_BATCH) images; allocated on
+ * first use, which synchronises the device once): a call on lane 1 shares no mutable state with a call on lane 0, so the two may be
+ * enqueued on DIFFERENT streams and execute concurrently -- TStarSearcher queues the NEXT iteration's grid forward (one image: 120-456
+ * wave tiles per GEMM for 1024 SIMDs) on lane 1 beside the verification batch of the iteration before (interface_searcher.py:444-491:
+ * the loop the reference runs strictly one call after another).  Calls on ONE lane must stay ordered (one stream, or events), as
+ * before.  Results do not depend on the lane: same kernels, same tile choices, same bits. */
+#define TSTAR_OWL_LANES 2
+#define TSTAR_OWL_AUX_BATCH 4
+int tstar_owl_score_lane(tstar_owl* h, int lane, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
+                         const int32_t* h_image_query_set, float* d_scores, int32_t* d_labels, float* d_boxes_xyxy,
+                         double* d_cell_conf, uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits,
+                         float* d_boxes_cxcywh, void* stream);
 
 /* Diagnostics for parity tests: the preprocessed 768x768 u8 image of the LAST chunk's image 0
  * (after bicubic) and its patch-embed A operand can be read back. */

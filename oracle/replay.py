@@ -24,8 +24,8 @@ class Recorder:
         self.calls = []
         self._orig = h.score_batch
 
-        def rec(d_images, rows, cols, image_sets=None):
-            r = self._orig(d_images, rows, cols, image_sets=image_sets)
+        def rec(d_images, rows, cols, image_sets=None, **kw):          # (lane=: the workspace of the forward, passed through)
+            r = self._orig(d_images, rows, cols, image_sets=image_sets, **kw)
             self.calls.append(dict(_res=r, rows=rows, cols=cols, images=d_images.cpu().numpy() if keep_images else None,
                                    conf=r.cell_conf.cpu().numpy(), mask=r.cell_mask.cpu().numpy().astype(np.uint32),
                                    scores=r.scores.cpu().numpy(), boxes=r.boxes.cpu().numpy(), labels=r.labels.cpu().numpy()))

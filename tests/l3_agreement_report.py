@@ -74,8 +74,8 @@ def run(args):
             orig, osb = s.sample_frames, h.score_batch
             s.sample_frames = lambda num, _o=orig: (lambda r: (log.append(list(r[0])), r)[1])(_o(num))
 
-            def rec(d_images, rows, cols, image_sets=None, _o=osb):
-                r = _o(d_images, rows, cols, image_sets=image_sets)
+            def rec(d_images, rows, cols, image_sets=None, _o=osb, **kw):
+                r = _o(d_images, rows, cols, image_sets=image_sets, **kw)
                 if rows == g:
                     confs.append(r.cell_conf.cpu().numpy()[0].reshape(g, g))
                 return r

@@ -191,6 +191,37 @@ def test_chunked_mixed_query_set_batch_equals_per_image_calls():
     sc.close()
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32x3"])
+def test_second_workspace_lane_same_bits_alone_and_concurrently(mode):
+    """Round 6: ``tstar_owl_score_lane`` -- lane 1 is a second, small activation workspace (forward chunks of 4 images) of the same
+    handle.  A forward in lane 1 gives the bits of the same forward in lane 0 (B = 1 and B = 6 = chunks of 4 + 2 against one chunk),
+    and a lane-1 grid forward enqueued on ANOTHER stream while a lane-0 verification-size batch is running returns the same bits as
+    when each runs alone (the two share no mutable state): what the searcher's speculative next-grid forward relies on."""
+    from tstar_amd.interface_heuristic import OWLInterface
+    h = OWLInterface(synthetic_seed=0, max_batch=16, weights_dtype=mode)
+    h.reparameterize_object_list(["couch"], ["tv", "chair"])
+    g = torch.Generator(device="cuda").manual_seed(11)
+    grid = torch.randint(0, 255, (1, 380, 800, 3), dtype=torch.uint8, device="cuda", generator=g)
+    ver = torch.randint(0, 255, (12, 285, 600, 3), dtype=torch.uint8, device="cuda", generator=g)
+    six = torch.randint(0, 255, (6, 285, 600, 3), dtype=torch.uint8, device="cuda", generator=g)
+    keys = ("scores", "labels", "boxes", "cell_conf", "cell_mask", "n_kept")
+    same = lambda a, b: all(torch.equal(getattr(a, k), getattr(b, k)) for k in keys)
+    g0, v0, s0 = h.score_batch(grid, 4, 4), h.score_batch(ver, 1, 1), h.score_batch(six, 1, 1)
+    g1, s1 = h.score_batch(grid, 4, 4, lane=1), h.score_batch(six, 1, 1, lane=1)
+    torch.cuda.synchronize()
+    assert same(g0, g1) and same(s0, s1)
+    aux = torch.cuda.Stream()
+    for _ in range(3):
+        aux.wait_stream(torch.cuda.current_stream())
+        vb = [h.score_batch(ver, 1, 1) for _ in range(3)]             # lane 0, this stream: ~20 ms of work
+        with torch.cuda.stream(aux):
+            gb = [h.score_batch(grid, 4, 4, lane=1) for _ in range(3)]     # lane 1, the other stream, at the same time
+        torch.cuda.synchronize()
+        assert all(same(v0, r) for r in vb) and all(same(g0, r) for r in gb)
+    with pytest.raises(Exception, match="lane must be 0 or 1"):
+        h.score_batch(grid, 4, 4, lane=2)
+
+
 def test_non_dyadic_class_weights_are_float64(setup):
     """object2weight is a constructor argument of the searcher (interface_searcher.py:31,88-91,136): with a weight such as
     0.7 the confidence ``np.float32 score * Python float`` is a float64 product under the reference's pinned numpy 1.26;

@@ -33,6 +33,7 @@ SIGNATURES = {
     "tstar_owl_set_class_weights": (_i, [_vp, _i, _vp, _i, _vp]),
     "tstar_owl_get_query_embeds": (_i, [_vp, _i, _vp, _i, _vp]),
     "tstar_owl_score": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tstar_owl_score_lane": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tstar_owl_debug_preprocess": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "tstar_yolo_create": (_i, [C.POINTER(_vp), _vp, _sz, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i]),
     "tstar_yolo_destroy": (_i, [_vp]),

@@ -86,17 +86,23 @@ struct tstar_owl {
     float* d_lut = nullptr;
     int max_batch = 0;
     size_t mpad = 0;
-    // activation workspace (per chunk of max_batch images)
-    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
-    uint8_t* tmp_u8 = nullptr; size_t tmp_u8_bytes = 0;
+    // activation workspaces (per chunk of `cap` images).  Lane 0 is the handle's own (max_batch images, allocated at creation; the
+    // text tower runs in it).  Lane 1 is a SMALL second one, allocated on first use (tstar_owl_score_lane): a forward that runs in it
+    // on another stream shares nothing mutable with a forward in lane 0, so the two may execute concurrently (the searcher's
+    // speculative next-grid forward, B = 1, beside the verification batch of the iteration before).
+    struct Lane {
+        float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+        uint8_t* tmp_u8 = nullptr; size_t tmp_u8_bytes = 0;
+        int* d_image_set = nullptr; int image_set_cap = 0;
+        int cap = 0;                                                 // images per forward chunk
+    } lane[TSTAR_OWL_LANES];
     // query sets: TSTAR_OWL_MAX_SETS independent (question) slots, each up to 32 queries; every image of
     // a score call names the slot it is scored against (several (video, question) items batched together)
     int Q[TSTAR_OWL_MAX_SETS] = {0};
     float *q_raw = nullptr, *qn = nullptr;                           // [sets][32][512]
     double* qweight = nullptr;                                       // [sets][32] object2weight per query (float64, as the reference's Python floats)
     uint8_t* qmask = nullptr;                                        // [sets][32]
-    int *d_setQ = nullptr, *d_image_set = nullptr;
-    int image_set_cap = 0;
+    int* d_setQ = nullptr;
     int *d_ids = nullptr, *d_eos = nullptr;
     uint8_t* d_kmask = nullptr;
     int seq_cap = TSTAR_OWL_MAX_QUERIES;                             // sequences the three staging buffers above hold
@@ -185,42 +191,58 @@ static bool x3_attention_f32() {
 }
 
 // CLIP pre-LN encoder stack shared by both towers; x [M,D] updated in place
-static int run_encoder(tstar_owl* h, const LayerW* layers, int nlayers, int B, int T, int D, int FF, int heads,
+static int run_encoder(tstar_owl* h, tstar_owl::Lane& L, const LayerW* layers, int nlayers, int B, int T, int D, int FF, int heads,
                        int mode, const uint8_t* key_mask, hipStream_t s) {
     const int M = B * T;
     for (int l = 0; l < nlayers; ++l) {
         const LayerW& w = layers[l];
-        RC(layernorm_f32(h->x, h->xn, w.ln1_w, w.ln1_b, M, D, s));
-        RC(gemm_f32(mk_gemm(h, h->xn, w.qkv_w, h->qkv, w.qkv_b, nullptr, M, 3 * D, D, D, 3 * D, ACT_NONE), s));
+        RC(layernorm_f32(L.x, L.xn, w.ln1_w, w.ln1_b, M, D, s));
+        RC(gemm_f32(mk_gemm(h, L.xn, w.qkv_w, L.qkv, w.qkv_b, nullptr, M, 3 * D, D, D, 3 * D, ACT_NONE), s));
         // full attention in the bf16-WEIGHT modes runs on the bf16 matrix pipe too (operands as two bf16 terms); in the f32x3
         // mode with all operand bits (three exact terms, six products: its claim is an error no larger than the f32 path's)
-        if (mode == 0 && (h->weights_mode == TSTAR_WEIGHTS_BF16 || h->weights_mode == TSTAR_WEIGHTS_BF16_EXACT)) RC(attention_split(h->qkv, h->att, B, T, heads, s));
-        else if (mode == 0 && h->weights_mode == TSTAR_WEIGHTS_F32X3 && !x3_attention_f32()) RC(attention_x3(h->qkv, h->att, B, T, heads, s));
-        else RC(attention_f32(h->qkv, h->att, B, T, heads, mode, key_mask, s));
-        RC(gemm_f32(mk_gemm(h, h->att, w.out_w, h->x, w.out_b, h->x, M, D, D, D, D, ACT_NONE), s));
-        RC(layernorm_f32(h->x, h->xn, w.ln2_w, w.ln2_b, M, D, s));
-        RC(gemm_f32(mk_gemm(h, h->xn, w.fc1_w, h->hid, w.fc1_b, nullptr, M, FF, D, D, FF, ACT_QGELU), s));
-        RC(gemm_f32(mk_gemm(h, h->hid, w.fc2_w, h->x, w.fc2_b, h->x, M, D, FF, FF, D, ACT_NONE), s));
+        if (mode == 0 && (h->weights_mode == TSTAR_WEIGHTS_BF16 || h->weights_mode == TSTAR_WEIGHTS_BF16_EXACT)) RC(attention_split(L.qkv, L.att, B, T, heads, s));
+        else if (mode == 0 && h->weights_mode == TSTAR_WEIGHTS_F32X3 && !x3_attention_f32()) RC(attention_x3(L.qkv, L.att, B, T, heads, s));
+        else RC(attention_f32(L.qkv, L.att, B, T, heads, mode, key_mask, s));
+        RC(gemm_f32(mk_gemm(h, L.att, w.out_w, L.x, w.out_b, L.x, M, D, D, D, D, ACT_NONE), s));
+        RC(layernorm_f32(L.x, L.xn, w.ln2_w, w.ln2_b, M, D, s));
+        RC(gemm_f32(mk_gemm(h, L.xn, w.fc1_w, L.hid, w.fc1_b, nullptr, M, FF, D, D, FF, ACT_QGELU), s));
+        RC(gemm_f32(mk_gemm(h, L.hid, w.fc2_w, L.x, w.fc2_b, L.x, M, D, FF, FF, D, ACT_NONE), s));
     }
     return TSTAR_OK;
 }
 
-static int preprocess_chunk(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, uint8_t* out_u8,
+static int preprocess_chunk(tstar_owl* h, tstar_owl::Lane& L, const uint8_t* d_images, int B, int H, int W, uint8_t* out_u8,
                             float* out_patches, hipStream_t s) {
     ResampleTable *th, *tv;
     RC(get_table(h, W, &th, s));
     RC(get_table(h, H, &tv, s));
     const size_t need = (size_t)B * H * 768 * 3;
-    if (need > h->tmp_u8_bytes) {
+    if (need > L.tmp_u8_bytes) {
         TSTAR_HIP_CHECK(hipStreamSynchronize(s));
-        if (h->tmp_u8) TSTAR_HIP_CHECK(hipFree(h->tmp_u8));
-        h->tmp_u8 = nullptr; h->tmp_u8_bytes = 0;
-        TSTAR_HIP_CHECK(hipMalloc(&h->tmp_u8, need));
-        h->tmp_u8_bytes = need;
+        if (L.tmp_u8) TSTAR_HIP_CHECK(hipFree(L.tmp_u8));
+        L.tmp_u8 = nullptr; L.tmp_u8_bytes = 0;
+        TSTAR_HIP_CHECK(hipMalloc(&L.tmp_u8, need));
+        L.tmp_u8_bytes = need;
     }
-    RC(resample_h_u8(d_images, h->tmp_u8, B, H, W, *th, s));
-    RC(resample_v_normalize_patchify(h->tmp_u8, out_patches, out_u8, B, H, *tv, h->d_lut, s));
+    RC(resample_h_u8(d_images, L.tmp_u8, B, H, W, *th, s));
+    RC(resample_v_normalize_patchify(L.tmp_u8, out_patches, out_u8, B, H, *tv, h->d_lut, s));
     return TSTAR_OK;
+}
+
+// One activation workspace for forward chunks of up to `cap` images: x, xn, att [Mp, 768], qkv [Mp, 2304], hid [Mp, 3072] with
+// Mp = roundup(cap * 577, 128); zero-filled (rows past M are read by the last GEMM tile of a launch).
+static hipError_t alloc_lane(tstar_owl::Lane& L, int cap) {
+    const size_t mp = round_up((size_t)cap * V_NTOK, 128);
+    hipError_t e = hipSuccess;
+    auto alloc = [&](float** p, size_t n) { if (e == hipSuccess) { e = hipMalloc(p, n * sizeof(float)); if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(float)); } };
+    alloc(&L.x, mp * V_D); alloc(&L.xn, mp * V_D); alloc(&L.qkv, mp * 3 * V_D); alloc(&L.att, mp * V_D); alloc(&L.hid, mp * V_FF);
+    if (e == hipSuccess) L.cap = cap;
+    return e;
+}
+static void free_lane(tstar_owl::Lane& L) {
+    void* ptrs[] = {L.x, L.xn, L.qkv, L.att, L.hid, L.tmp_u8, L.d_image_set};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    L = tstar_owl::Lane{};
 }
 
 extern "C" {
@@ -295,11 +317,9 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
     }
     h->max_batch = max_batch;
     h->mpad = round_up((size_t)max_batch * V_NTOK, 128);
-    const size_t mp = h->mpad;
     hipError_t e = hipSuccess;
     auto alloc = [&](float** p, size_t n) { if (e == hipSuccess) { e = hipMalloc(p, n * sizeof(float)); if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(float)); } };
-    alloc(&h->x, mp * V_D); alloc(&h->xn, mp * V_D); alloc(&h->qkv, mp * 3 * V_D); alloc(&h->att, mp * V_D);
-    alloc(&h->hid, mp * V_FF);
+    e = alloc_lane(h->lane[0], max_batch);
     alloc(&h->d_lut, 768);
     constexpr int NSQ = TSTAR_OWL_MAX_SETS * TSTAR_OWL_MAX_QUERIES;
     alloc(&h->q_raw, (size_t)NSQ * PROJ); alloc(&h->qn, (size_t)NSQ * PROJ);
@@ -328,9 +348,9 @@ int tstar_owl_create(tstar_owl** out, const float* h_vision_blob, size_t n_visio
 
 int tstar_owl_destroy(tstar_owl* h) {
     if (!h) return TSTAR_OK;
-    void* ptrs[] = {h->d_vision, h->d_text, h->d_lut, h->x, h->xn, h->qkv, h->att, h->hid, h->tmp_u8, h->q_raw,
-                    h->qn, h->qweight, h->qmask, h->d_ids, h->d_eos, h->d_kmask, h->d_setQ, h->d_image_set};
+    void* ptrs[] = {h->d_vision, h->d_text, h->d_lut, h->q_raw, h->qn, h->qweight, h->qmask, h->d_ids, h->d_eos, h->d_kmask, h->d_setQ};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& L : h->lane) free_lane(L);
     for (auto& kv : h->tabs) free_table(&kv.second);
     for (auto& kv : h->wb) if (kv.second) (void)hipFree(kv.second);
     for (auto& kv : h->wp) if (kv.second) (void)hipFree(kv.second);
@@ -359,6 +379,7 @@ int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_ids, con
     TSTAR_REQUIRE(Q >= 1 && Q <= TSTAR_OWL_MAX_QUERIES, "tstar_owl_set_queries: Q must be in 1..32");
     if (!h->has_text) { set_error("tstar_owl_set_queries: handle was created without text weights"); return TSTAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
+    auto& L = h->lane[0];                                      // the text tower runs in the handle's own workspace
     std::vector<int> eos(Q);
     std::vector<uint8_t> km(Q * T_LEN), qm(Q);
     for (int q = 0; q < Q; ++q) {
@@ -376,15 +397,15 @@ int tstar_owl_set_queries(tstar_owl* h, int query_set, const int32_t* h_ids, con
     TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_eos, eos.data(), Q * sizeof(int), hipMemcpyHostToDevice, s));
     TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_kmask, km.data(), Q * T_LEN, hipMemcpyHostToDevice, s));
     const int M = Q * T_LEN;
-    hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(128), 0, s, h->d_ids, h->tw.tok_emb, h->tw.tpos_emb, h->x,
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(128), 0, s, h->d_ids, h->tw.tok_emb, h->tw.tpos_emb, L.x,
                        T_LEN, T_D);
     TSTAR_HIP_CHECK(hipGetLastError());
-    RC(run_encoder(h, h->tw.layers, T_LAYERS, Q, T_LEN, T_D, T_FF, T_HEADS, 1, h->d_kmask, s));
-    RC(layernorm_f32(h->x, h->xn, h->tw.final_ln_w, h->tw.final_ln_b, M, T_D, s));
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(Q), dim3(128), 0, s, h->xn, h->d_eos, h->att, T_LEN, T_D);
+    RC(run_encoder(h, L, h->tw.layers, T_LAYERS, Q, T_LEN, T_D, T_FF, T_HEADS, 1, h->d_kmask, s));
+    RC(layernorm_f32(L.x, L.xn, h->tw.final_ln_w, h->tw.final_ln_b, M, T_D, s));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(Q), dim3(128), 0, s, L.xn, h->d_eos, L.att, T_LEN, T_D);
     TSTAR_HIP_CHECK(hipGetLastError());
-    RC(gemm_f32(mk_gemm(h, h->att, h->tw.text_proj, h->hid, nullptr, nullptr, Q, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->hid,
+    RC(gemm_f32(mk_gemm(h, L.att, h->tw.text_proj, L.hid, nullptr, nullptr, Q, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, L.hid,
                        h->q_raw + (size_t)query_set * TSTAR_OWL_MAX_QUERIES * PROJ, 0.0f);
     TSTAR_HIP_CHECK(hipGetLastError());
     return finish_queries(h, query_set, qm.data(), h_w, Q, s);
@@ -396,6 +417,7 @@ int tstar_owl_set_queries_many(tstar_owl* h, int n_sets, const int32_t* h_sets, 
     TSTAR_REQUIRE(n_sets >= 1 && n_sets <= TSTAR_OWL_MAX_SETS, "tstar_owl_set_queries_many: n_sets must be in 1..64");
     if (!h->has_text) { set_error("tstar_owl_set_queries_many: handle was created without text weights"); return TSTAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
+    auto& L = h->lane[0];
     int total = 0;
     for (int i = 0; i < n_sets; ++i) {
         CHECK_SET(h_sets[i], "tstar_owl_set_queries_many");
@@ -438,18 +460,18 @@ int tstar_owl_set_queries_many(tstar_owl* h, int n_sets, const int32_t* h_sets, 
         TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_ids, h_ids + (size_t)q0 * T_LEN, (size_t)M * sizeof(int), hipMemcpyHostToDevice, s));
         TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_eos, eos.data() + q0, nseq * sizeof(int), hipMemcpyHostToDevice, s));
         TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_kmask, km.data() + (size_t)q0 * T_LEN, M, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(128), 0, s, h->d_ids, h->tw.tok_emb, h->tw.tpos_emb, h->x, T_LEN, T_D);
+        hipLaunchKernelGGL(embed_tokens_kernel, dim3(M), dim3(128), 0, s, h->d_ids, h->tw.tok_emb, h->tw.tpos_emb, L.x, T_LEN, T_D);
         TSTAR_HIP_CHECK(hipGetLastError());
-        RC(run_encoder(h, h->tw.layers, T_LAYERS, nseq, T_LEN, T_D, T_FF, T_HEADS, 1, h->d_kmask, s));
-        RC(layernorm_f32(h->x, h->xn, h->tw.final_ln_w, h->tw.final_ln_b, M, T_D, s));
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(nseq), dim3(128), 0, s, h->xn, h->d_eos, h->att, T_LEN, T_D);
+        RC(run_encoder(h, L, h->tw.layers, T_LAYERS, nseq, T_LEN, T_D, T_FF, T_HEADS, 1, h->d_kmask, s));
+        RC(layernorm_f32(L.x, L.xn, h->tw.final_ln_w, h->tw.final_ln_b, M, T_D, s));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(nseq), dim3(128), 0, s, L.xn, h->d_eos, L.att, T_LEN, T_D);
         TSTAR_HIP_CHECK(hipGetLastError());
-        RC(gemm_f32(mk_gemm(h, h->att, h->tw.text_proj, h->hid, nullptr, nullptr, nseq, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
+        RC(gemm_f32(mk_gemm(h, L.att, h->tw.text_proj, L.hid, nullptr, nullptr, nseq, PROJ, T_D, T_D, PROJ, ACT_NONE), s));
         int off = 0;
         for (int i = i0; i < i1; ++i) {
             const int set = h_sets[i], Q = h_Q[i];
             const size_t qo = (size_t)set * TSTAR_OWL_MAX_QUERIES;
-            hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->hid + (size_t)off * PROJ, h->q_raw + qo * PROJ, 0.0f);
+            hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, L.hid + (size_t)off * PROJ, h->q_raw + qo * PROJ, 0.0f);
             hipLaunchKernelGGL(l2norm_rows_kernel, dim3(Q), dim3(64), 0, s, h->q_raw + qo * PROJ, h->qn + qo * PROJ, 1e-6f);
             TSTAR_HIP_CHECK(hipGetLastError());
             TSTAR_HIP_CHECK(hipMemcpyAsync(h->qmask + qo, qm.data() + q0 + off, Q, hipMemcpyHostToDevice, s));
@@ -503,12 +525,31 @@ int tstar_owl_get_query_embeds(tstar_owl* h, int query_set, float* h_out, int Q,
 int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
                     const int32_t* h_image_query_set, float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
                     uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits, float* d_boxes_cxcywh, void* stream) {
+    return tstar_owl_score_lane(h, 0, d_images, B, H, W, grid_rows, grid_cols, h_image_query_set, d_scores, d_labels, d_boxes_xyxy, d_cell_conf,
+                                d_cell_mask, d_n_kept, d_logits, d_boxes_cxcywh, stream);
+}
+
+int tstar_owl_score_lane(tstar_owl* h, int lane, const uint8_t* d_images, int B, int H, int W, int grid_rows, int grid_cols,
+                         const int32_t* h_image_query_set, float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
+                         uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits, float* d_boxes_cxcywh, void* stream) {
     TSTAR_REQUIRE(h && d_images && d_scores && d_labels && d_boxes_xyxy && d_cell_conf && d_cell_mask,
                   "tstar_owl_score: null argument");
+    TSTAR_REQUIRE(lane >= 0 && lane < TSTAR_OWL_LANES, "tstar_owl_score_lane: lane must be 0 or 1");
     TSTAR_REQUIRE(B >= 1 && H >= 1 && W >= 1, "tstar_owl_score: empty batch or image");
     TSTAR_REQUIRE(grid_rows >= 1 && grid_cols >= 1, "tstar_owl_score: grid must be at least 1x1");
     if (!h->has_vision) { set_error("tstar_owl_score: handle was created without vision weights (text-only)"); return TSTAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
+    auto& L = h->lane[lane];
+    if (!L.x) {                                           // lane 1: allocated on first use (a one-off, like the resample tables)
+        const int cap = h->max_batch < TSTAR_OWL_AUX_BATCH ? h->max_batch : TSTAR_OWL_AUX_BATCH;
+        const hipError_t e = alloc_lane(L, cap);
+        if (e != hipSuccess) {
+            free_lane(L);
+            set_error(std::string("tstar_owl_score_lane: workspace allocation failed: ") + hipGetErrorString(e));
+            return TSTAR_ERR_HIP;
+        }
+        TSTAR_HIP_CHECK(hipDeviceSynchronize());          // the zero fill ran on the null stream
+    }
     int q_uniform = -1;                                   // the common Q when every image uses one set size
     for (int b = 0; b < B; ++b) {
         const int set = h_image_query_set ? h_image_query_set[b] : 0;
@@ -518,31 +559,31 @@ int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, 
     }
     TSTAR_REQUIRE(!d_logits || q_uniform > 0, "tstar_owl_score: raw logits need the same query count for every image");
     if (h_image_query_set) {
-        if (B > h->image_set_cap) {
+        if (B > L.image_set_cap) {
             TSTAR_HIP_CHECK(hipStreamSynchronize(s));
-            if (h->d_image_set) TSTAR_HIP_CHECK(hipFree(h->d_image_set));
-            h->d_image_set = nullptr; h->image_set_cap = 0;
-            TSTAR_HIP_CHECK(hipMalloc(&h->d_image_set, (size_t)B * sizeof(int)));
-            h->image_set_cap = B;
+            if (L.d_image_set) TSTAR_HIP_CHECK(hipFree(L.d_image_set));
+            L.d_image_set = nullptr; L.image_set_cap = 0;
+            TSTAR_HIP_CHECK(hipMalloc(&L.d_image_set, (size_t)B * sizeof(int)));
+            L.image_set_cap = B;
         }
-        TSTAR_HIP_CHECK(hipMemcpyAsync(h->d_image_set, h_image_query_set, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+        TSTAR_HIP_CHECK(hipMemcpyAsync(L.d_image_set, h_image_query_set, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
     }
     const int ncell = grid_rows * grid_cols;
-    for (int b0 = 0; b0 < B; b0 += h->max_batch) {
-        const int Bc = (B - b0) < h->max_batch ? (B - b0) : h->max_batch;
+    for (int b0 = 0; b0 < B; b0 += L.cap) {
+        const int Bc = (B - b0) < L.cap ? (B - b0) : L.cap;
         const int M = Bc * V_NTOK, MP = Bc * V_NP;
-        RC(preprocess_chunk(h, d_images + (size_t)b0 * H * W * 3, Bc, H, W, nullptr, h->hid, s));
-        GemmArgs pg = mk_gemm(h, h->hid, h->vw.patch_w, h->x, nullptr, nullptr, MP, V_D, V_PATCH_K, V_PATCH_K, V_D, ACT_NONE);
+        RC(preprocess_chunk(h, L, d_images + (size_t)b0 * H * W * 3, Bc, H, W, nullptr, L.hid, s));
+        GemmArgs pg = mk_gemm(h, L.hid, h->vw.patch_w, L.x, nullptr, nullptr, MP, V_D, V_PATCH_K, V_PATCH_K, V_D, ACT_NONE);
         pg.pos = h->vw.pos_emb; pg.patch_np = V_NP;
         RC(gemm_f32(pg, s));
-        RC(write_cls_rows(h->x, h->vw.class_emb, h->vw.pos_emb, Bc, V_NTOK, V_D, s));
-        RC(layernorm_f32(h->x, h->x, h->vw.pre_ln_w, h->vw.pre_ln_b, M, V_D, s));
-        RC(run_encoder(h, h->vw.layers, V_LAYERS, Bc, V_NTOK, V_D, V_FF, V_HEADS, 0, nullptr, s));
-        float* feats = h->xn;
-        RC(merge_cls_ln(h->x, feats, h->vw.post_ln_w, h->vw.post_ln_b, h->vw.det_ln_w, h->vw.det_ln_b, Bc, V_NTOK, V_D, s));
-        float* cls = h->att;      // [MP, 512]
-        float* bh1 = h->qkv;      // [MP, 768]
-        float* bh2 = h->hid;      // [MP, 768]
+        RC(write_cls_rows(L.x, h->vw.class_emb, h->vw.pos_emb, Bc, V_NTOK, V_D, s));
+        RC(layernorm_f32(L.x, L.x, h->vw.pre_ln_w, h->vw.pre_ln_b, M, V_D, s));
+        RC(run_encoder(h, L, h->vw.layers, V_LAYERS, Bc, V_NTOK, V_D, V_FF, V_HEADS, 0, nullptr, s));
+        float* feats = L.xn;
+        RC(merge_cls_ln(L.x, feats, h->vw.post_ln_w, h->vw.post_ln_b, h->vw.det_ln_w, h->vw.det_ln_b, Bc, V_NTOK, V_D, s));
+        float* cls = L.att;      // [MP, 512]
+        float* bh1 = L.qkv;      // [MP, 768]
+        float* bh2 = L.hid;      // [MP, 768]
         RC(gemm_f32(mk_gemm(h, feats, h->vw.cls_w, cls, h->vw.cls_b, nullptr, MP, PROJ, V_D, V_D, PROJ, ACT_NONE), s));
         RC(gemm_f32(mk_gemm(h, feats, h->vw.box0_w, bh1, h->vw.box0_b, nullptr, MP, V_D, V_D, V_D, V_D, ACT_GELU), s));
         RC(gemm_f32(mk_gemm(h, bh1, h->vw.box1_w, bh2, h->vw.box1_b, nullptr, MP, V_D, V_D, V_D, V_D, ACT_GELU), s));
@@ -554,7 +595,7 @@ int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, 
         a.labels = d_labels + (size_t)b0 * V_NP;
         a.xyxy = d_boxes_xyxy + (size_t)b0 * V_NP * 4;
         a.logits = d_logits ? d_logits + (size_t)b0 * V_NP * q_uniform : nullptr;
-        a.image_set = h_image_query_set ? h->d_image_set + b0 : nullptr;
+        a.image_set = h_image_query_set ? L.d_image_set + b0 : nullptr;
         a.setQ = h->d_setQ;
         a.cxcywh = d_boxes_cxcywh ? d_boxes_cxcywh + (size_t)b0 * V_NP * 4 : nullptr;
         a.rows = MP; a.np = V_NP; a.Q = q_uniform; a.img_w = W; a.img_h = H;
@@ -571,7 +612,7 @@ int tstar_owl_debug_preprocess(tstar_owl* h, const uint8_t* d_images, int B, int
     TSTAR_REQUIRE(h && d_images && d_out_patches, "tstar_owl_debug_preprocess: null argument");
     TSTAR_REQUIRE(B >= 1 && B <= h->max_batch, "tstar_owl_debug_preprocess: B must be in 1..max_batch");
     if (!h->has_vision) { set_error("tstar_owl_debug_preprocess: handle was created without vision weights (text-only)"); return TSTAR_ERR_STATE; }
-    return preprocess_chunk(h, d_images, B, H, W, d_out_u8, d_out_patches, (hipStream_t)stream);
+    return preprocess_chunk(h, h->lane[0], d_images, B, H, W, d_out_u8, d_out_patches, (hipStream_t)stream);
 }
 
 int tstar_frames_to_grid(const uint8_t* d_video, int N, int H, int W, const int32_t* d_frame_idx, int grid_rows,

@@ -182,10 +182,12 @@ class OWLInterface(HeuristicInterface):
         self.scorer.set_class_weights(w)
         self._class_weight = np.asarray(w, dtype=np.float64)
 
-    def score_batch(self, d_images, grid_rows: int, grid_cols: int, image_sets=None):
+    aux_lane = True      # score_batch(..., lane=1) runs in a second workspace: safe to enqueue on another stream beside lane 0
+
+    def score_batch(self, d_images, grid_rows: int, grid_cols: int, image_sets=None, lane: int = 0):
         """Batched scoring of device images u8 [B,H,W,3] -> tstar_amd.owl.ScoreResult (device tensors).
-        ``image_sets``: query-set slot per image (see ``install_queries``); default slot 0."""
-        return self.scorer.score(d_images, grid_rows, grid_cols, image_sets=image_sets)
+        ``image_sets``: query-set slot per image (see ``install_queries``); default slot 0.  ``lane``: see ``OwlScorer.score``."""
+        return self.scorer.score(d_images, grid_rows, grid_cols, image_sets=image_sets, lane=lane)
 
     def install_queries(self, slot: int, target_objects: List[str], cue_objects: List[str],
                         object2weight: Optional[Dict[str, float]] = None) -> List[List[str]]:

@@ -31,7 +31,12 @@ from .interface_searcher import SAMPLER_WARNING, TStarSearcher
 MAX_GROUP = 63          # TSTAR_OWL_MAX_SETS - 1 query-set slots (include/tstar_hip.h); slot 0 stays the heuristic's own
 
 _SIDE = {}              # device index -> the side stream of the searcher-state kernels
+_AUX = {}               # device index -> the stream of the speculative next-grid forwards (workspace lane 1)
 _SPECULATE = os.environ.get("TSTAR_NO_SPECULATION") is None      # TSTAR_NO_SPECULATION=1: same-session A/Bs of speculate()
+# Round 6: the speculative forward runs BESIDE the verification batch -- its own stream, the detector's second workspace (lane 1) --
+# instead of behind it on the detector stream.  TSTAR_SPECULATE_BEHIND=1 restores round 5's placement (same-session A/Bs).
+_BESIDE = os.environ.get("TSTAR_SPECULATE_BEHIND") is None
+AUX_IMAGES = 4          # TSTAR_OWL_AUX_BATCH (include/tstar_hip.h): images per forward chunk of lane 1
 
 
 def _side_stream(torch):
@@ -39,6 +44,24 @@ def _side_stream(torch):
     if d not in _SIDE:
         _SIDE[d] = torch.cuda.Stream(device=d)
     return _SIDE[d]
+
+
+def _accepts_lane(fn) -> bool:
+    """A wrapper installed over ``heuristic.score_batch`` (a recorder, a logger) with the pre-round-6 signature keeps working: the
+    speculative forward then stays on the detector stream."""
+    import inspect
+    try:
+        ps = inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+    return "lane" in ps or any(p.kind == inspect.Parameter.VAR_KEYWORD for p in ps.values())
+
+
+def _aux_stream(torch):
+    d = torch.cuda.current_device()
+    if d not in _AUX:
+        _AUX[d] = torch.cuda.Stream(device=d)
+    return _AUX[d]
 
 
 class _Group:
@@ -55,6 +78,8 @@ class _Group:
             s._slot = first_slot + i
         self.main = torch.cuda.current_stream()
         self.side = _side_stream(torch)
+        # speculative forwards beside the verification batch: only a detector with a second workspace (OWLInterface.aux_lane)
+        self.aux = _aux_stream(torch) if (_BESIDE and getattr(self.h, "aux_lane", False) and _accepts_lane(self.h.score_batch)) else None
         self.pending = None            # the verification batch in flight (end() consumes it)
         self.act = []
         self.spec = None               # the NEXT iteration's samples / grid forward, queued speculatively (see speculate())
@@ -64,6 +89,8 @@ class _Group:
         h = self.h
         self.side.wait_stream(self.main)          # state written on the caller's stream before the search (once: a wait per
                                                   # iteration would queue the samples behind the other group's batch)
+        if self.aux is not None:
+            self.aux.wait_stream(self.main)       # (the resident video may have been produced on the caller's stream just before)
         if self.solo:                             # the searcher's own question sits in slot 0 since its constructor
             self.act = self._active()
             return
@@ -165,11 +192,22 @@ class _Group:
                 secs_l.append(s._sample_secs(self.n, _warned=w))   # NOT the public hook, and no warning printed: a discarded draw must stay invisible
                 warned.append(bool(w and w[0]))
                 s.search_budget -= self.n
-        for s, secs in zip(items, secs_l):
-            grids.append(s._device_grid(secs))
-        res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(items))
-        ev = torch.cuda.Event()
-        ev.record(self.main)
+        # Where the forward runs.  Behind the verification batch on the detector stream it would wait for it; the B = 1 forward of a search
+        # running alone launches 120-456 wave tiles per GEMM for 1024 SIMDs and a verification batch of ~10 images as few as ~140 wide
+        # blocks for 256 CUs -- side by side (another stream, the detector's second workspace: tstar_owl_score_lane) each fills what the
+        # other leaves idle.  Same kernels, same tiles, same bits; lane 1 holds forward chunks of AUX_IMAGES images, so larger groups
+        # keep the round-5 placement.
+        beside = self.aux is not None and len(items) <= AUX_IMAGES
+        stream = self.aux if beside else self.main
+        with torch.cuda.stream(stream):
+            for s, secs in zip(items, secs_l):
+                grids.append(s._device_grid(secs))
+            if beside:
+                res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(items), lane=1)
+            else:
+                res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(items))
+            ev = torch.cuda.Event()
+            ev.record(stream)
         self.spec = (items, secs_l, grids, res, ev, states, warned)
 
     def _drop_speculation(self):
@@ -274,6 +312,8 @@ class _Group:
                 s.last_time_stamps = list(ts)
                 out.append((frames, ts))
         self.main.wait_stream(self.side)          # whoever uses the searchers next on this stream sees the final state
+        if self.aux is not None:
+            self.main.wait_stream(self.aux)       # ... and finds lane 1 idle (a dropped speculative forward may still be running)
         return out
 
 

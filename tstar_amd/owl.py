@@ -195,9 +195,10 @@ class OwlScorer:
 
     # ---- scoring
     def score(self, images, grid_rows: int, grid_cols: int, want_logits: bool = False,
-              image_sets: Optional[Sequence[int]] = None) -> ScoreResult:
+              image_sets: Optional[Sequence[int]] = None, lane: int = 0) -> ScoreResult:
         """images: torch u8 cuda tensor [B,H,W,3] (contiguous); ``image_sets``: query-set slot per image
-        (default: slot 0 for all)."""
+        (default: slot 0 for all).  ``lane``: activation workspace of the forward (tstar_owl_score_lane) -- 0 = the handle's own,
+        1 = the small second one: a call on lane 1 enqueued on ANOTHER stream may run beside a call on lane 0 (same results)."""
         torch = self._torch
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3 or not images.is_cuda:
             raise ValueError("score: images must be a cuda uint8 tensor [B,H,W,3]")
@@ -228,8 +229,8 @@ class OwlScorer:
                 raise ValueError("score: raw logits need the same query count for every image")
             r.logits = torch.empty((B, W.NPATCH, qs.pop()), dtype=torch.float32, device=dev)
             r.boxes_cxcywh = torch.empty((B, W.NPATCH, 4), dtype=torch.float32, device=dev)
-        rc = self._lib.tstar_owl_score(
-            self._h, images.data_ptr(), B, H, Wd, grid_rows, grid_cols,
+        rc = self._lib.tstar_owl_score_lane(
+            self._h, int(lane), images.data_ptr(), B, H, Wd, grid_rows, grid_cols,
             None if sets is None else sets.ctypes.data, r.scores.data_ptr(), r.labels.data_ptr(), r.boxes.data_ptr(), r.cell_conf.data_ptr(),
             r.cell_mask.data_ptr(), r.n_kept.data_ptr(),
             _lib.ptr(r.logits), _lib.ptr(r.boxes_cxcywh), _lib.stream_ptr())
