@@ -68,25 +68,7 @@ __device__ __forceinline__ void split4_rn(const f32x4 v, u32x2 (&out)[NA]) {
 }
 // one pair of floats -> three packed bf16 pairs (round-to-nearest terms of the running remainder); scalar subtractions:
 // packed f32 VALU beside MFMAs costs more than its issue slot (MI355X guide)
-#ifndef TSTAR_SPLIT_DOT2
-#define TSTAR_SPLIT_DOT2 0
-#endif
 __device__ __forceinline__ void split2_rn3(float x0, float x1, unsigned (&o)[3]) {
-#if TSTAR_SPLIT_DOT2
-    // remainders by v_dot2c_f32_bf16: r = dot2((t.lo, t.hi), (-1, 0)) + x -- the difference is exactly representable, one rounding: the same
-    // bits as the subtract form (tools/lab/dot2_split_lab.hip), without the shift / mask that form needs to widen the bf16 halves
-    const bf16x2 nlo = __builtin_bit_cast(bf16x2, 0x0000BF80u), nhi = __builtin_bit_cast(bf16x2, 0xBF800000u);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        f32x2 x; x[0] = x0; x[1] = x1;
-        const bf16x2 b = __builtin_convertvector(x, bf16x2);
-        o[k] = __builtin_bit_cast(unsigned, b);
-        if (k < 2) {
-            x0 = __builtin_amdgcn_fdot2_f32_bf16(b, nlo, x0, false);
-            x1 = __builtin_amdgcn_fdot2_f32_bf16(b, nhi, x1, false);
-        }
-    }
-#else
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         f32x2 x; x[0] = x0; x[1] = x1;
@@ -97,7 +79,6 @@ __device__ __forceinline__ void split2_rn3(float x0, float x1, unsigned (&o)[3])
             x1 = x1 - __uint_as_float(hb & 0xFFFF0000u);
         }
     }
-#endif
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }

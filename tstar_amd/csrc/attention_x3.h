@@ -48,25 +48,7 @@ constexpr int LDS_BYTES = NKB * KBUF + NVB * VBUF;      // 69 KB
 #define AX3_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // (x0, x1) -> three packed bf16 pairs: round-to-nearest terms of the running remainder (the third is exact)
-#ifndef TSTAR_SPLIT_DOT2
-#define TSTAR_SPLIT_DOT2 0
-#endif
 __device__ __forceinline__ void split2_rn3(float x0, float x1, unsigned (&o)[3]) {
-#if TSTAR_SPLIT_DOT2
-    // remainders by v_dot2c_f32_bf16: r = dot2((t.lo, t.hi), (-1, 0)) + x -- the difference is exactly representable, one rounding: the same
-    // bits as the subtract form (tools/lab/dot2_split_lab.hip), without the shift / mask that form needs to widen the bf16 halves
-    const bf16x2 nlo = __builtin_bit_cast(bf16x2, 0x0000BF80u), nhi = __builtin_bit_cast(bf16x2, 0xBF800000u);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        f32x2 x; x[0] = x0; x[1] = x1;
-        const bf16x2 b = __builtin_convertvector(x, bf16x2);
-        o[k] = __builtin_bit_cast(unsigned, b);
-        if (k < 2) {
-            x0 = __builtin_amdgcn_fdot2_f32_bf16(b, nlo, x0, false);
-            x1 = __builtin_amdgcn_fdot2_f32_bf16(b, nhi, x1, false);
-        }
-    }
-#else
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         f32x2 x; x[0] = x0; x[1] = x1;
@@ -77,7 +59,6 @@ __device__ __forceinline__ void split2_rn3(float x0, float x1, unsigned (&o)[3])
             x1 = x1 - __uint_as_float(hb & 0xFFFF0000u);
         }
     }
-#endif
 }
 // value of lane ^ 32 combined with this lane's, without the LDS pipe (gfx950 v_permlane32_swap)
 __device__ __forceinline__ float xhalf_max(float x) {
