@@ -36,6 +36,9 @@ _SPECULATE = os.environ.get("TSTAR_NO_SPECULATION") is None      # TSTAR_NO_SPEC
 # Round 6: the speculative forward runs BESIDE the verification batch -- its own stream, the detector's second workspace (lane 1) --
 # instead of behind it on the detector stream.  TSTAR_SPECULATE_BEHIND=1 restores round 5's placement (same-session A/Bs).
 _BESIDE = os.environ.get("TSTAR_SPECULATE_BEHIND") is None
+# ... and the next verification batch is queued behind the running one before its results are read (verify_ahead()).
+# TSTAR_NO_VERIFY_AHEAD=1: off (same-session A/Bs).
+_AHEAD = os.environ.get("TSTAR_NO_VERIFY_AHEAD") is None
 AUX_IMAGES = 4          # TSTAR_OWL_AUX_BATCH (include/tstar_hip.h): images per forward chunk of lane 1
 
 
@@ -83,6 +86,8 @@ class _Group:
         self.pending = None            # the verification batch in flight (end() consumes it)
         self.act = []
         self.spec = None               # the NEXT iteration's samples / grid forward, queued speculatively (see speculate())
+        self.ahead = None              # ... and its verification batch, queued behind the one in flight (see verify_ahead())
+        self.vq = self.masks = None    # the verification batch of THIS iteration (verify_launch()) and the grid's cell masks
         self.solo = False              # one searcher driven through its own slot 0 and its public sample_frames hook
 
     def install(self):
@@ -149,6 +154,8 @@ class _Group:
                 return
             # an override changed (or replaced) the draw: the iteration runs on ITS samples, as in the sequential loop; the
             # speculated forward is dropped (the image did go through the detector).  The budget was already charged.
+            if self.ahead is not None:
+                self._drop_ahead()                # (chosen from the dropped forward's masks)
             s.device_images_scored += 1
             cb = getattr(self.h, "_speculation_dropped", None)
             if cb is not None:
@@ -211,6 +218,8 @@ class _Group:
         self.spec = (items, secs_l, grids, res, ev, states, warned)
 
     def _drop_speculation(self):
+        if self.ahead is not None:
+            self._drop_ahead()
         items, _, _, res, _, states, _ = self.spec
         self.spec = None
         for s, st in zip(items, states):
@@ -221,27 +230,25 @@ class _Group:
         if cb is not None:
             cb(res)
 
-    def middle(self):
-        """Wait for the grid forward; the verification batch (detector stream) and, under its shadow, the score write-back
-        (side stream), the FITPACK fits, P and the histories."""
-        torch, h, act, res, secs_l, n = self.torch, self.h, self.act, self.res, self.secs_l, self.n
-        names_l, fits, cand_l = [], [], []
+    def _verify_queue(self, act, secs_l, res, ev_grid):
+        """Wait for a grid forward's cell masks and queue the verification batch they call for on the detector stream:
+        -> (masks, (vres, vframes, event, candidates per item, row offsets, the remaining targets the candidates were chosen for))."""
+        torch, h = self.torch, self.h
         with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_grid)
+            self.side.wait_event(ev_grid)
             masks = res.cell_mask.cpu().numpy().astype(np.uint32)
+        cand_l = []
         for i, s in enumerate(act):
             # candidates of the verification batch: cells whose mask lists a remaining target (the same test as
-            # ``any(t in names ...)`` on the decoded names, which are only needed by the replay and are built below)
+            # ``any(t in names ...)`` on the decoded names, which are only needed by the replay and are built in update())
             tb = 0
             for q, t in enumerate(s._texts):
                 if t[0] in s.remaining_targets:
                     tb |= 1 << q
             cand_l.append(np.nonzero(masks[i][:len(secs_l[i])] & np.uint32(tb))[0].tolist())
-        # ONE verification batch for every item of the group (device work only), queued before anything else: it needs the
-        # cell masks only, and the detector stream is empty until it arrives ...
-        vres = vframes = None
+        # ONE verification batch for every item of the group (device work only): it needs the cell masks only
+        vres = vframes = ev = None
         offs = np.cumsum([0] + [len(c) for c in cand_l])
-        ev = None
         if offs[-1] > 0:
             vframes = torch.cat([s._device_verify_frames([secs_l[i][j] for j in cand_l[i]])
                                  for i, s in enumerate(act) if cand_l[i]])
@@ -249,7 +256,55 @@ class _Group:
             vres = h.score_batch(vframes, 1, 1, image_sets=sets)
             ev = torch.cuda.Event()
             ev.record(self.main)
-        # ... then the grid scores go into the per-item state (write-back, window spread, visited list: side stream) ...
+        return masks, (vres, vframes, ev, cand_l, offs, [list(s.remaining_targets) for s in act])
+
+    def middle(self):
+        """Wait for the grid forward; the verification batch (detector stream) and, under its shadow, the score write-back
+        (side stream), the FITPACK fits, P and the histories."""
+        self.verify_launch()
+        self.update()
+
+    def verify_launch(self):
+        """The iteration's verification batch, queued before anything else of ``middle()``: the detector stream is empty until it
+        arrives -- unless ``verify_ahead()`` already queued exactly this batch behind the previous one."""
+        if self.ahead is not None:
+            self.masks, self.vq = self.ahead
+            self.ahead = None
+            return
+        self.masks, self.vq = self._verify_queue(self.act, self.secs_l, self.res, self.ev_grid)
+
+    def verify_ahead(self):
+        """Round 6, a search running alone: queue the NEXT iteration's verification batch as soon as its (speculative) grid forward is
+        back -- behind the verification batch that is still running, BEFORE that batch's results are read -- so that the detector stream
+        goes from one verification batch straight into the next and the host's replay / write-back / fit run in its shadow.  Valid
+        because the candidates of a verification batch are the cells of the NEXT grid image that list a remaining target
+        (interface_searcher.py:481-486): they depend on this iteration's verification only through ``remaining_targets``.  ``end()``
+        keeps the batch if the replay left ``remaining_targets`` as they were when the candidates were chosen; if a target was
+        found, the batch is dropped (the search is over, or ``verify_launch()`` queues the smaller batch of the sequential loop)."""
+        if self.spec is None or self.ahead is not None:
+            return
+        items, secs_l, _, res, ev, _, _ = self.spec
+        self.ahead = self._verify_queue(items, secs_l, res, ev)
+
+    def verification_done(self) -> bool:
+        """Has the verification batch in flight already finished (nothing would be gained by queueing the next one behind it)?"""
+        ev = self.vq[2] if self.vq is not None else None
+        return ev is None or ev.query()
+
+    def _drop_ahead(self):
+        _, (vres, _, _, cand_l, _, _) = self.ahead
+        self.ahead = None
+        for s, c in zip(self.spec[0] if self.spec is not None else self.act, cand_l):
+            s.device_images_scored += len(c)      # the frames did go through the detector
+        cb = getattr(self.h, "_speculation_dropped", None)
+        if cb is not None and vres is not None:
+            cb(vres)
+
+    def update(self):
+        """The grid scores go into the per-item state (write-back, window spread, visited list: side stream) while the host builds the
+        sampling distributions; histories."""
+        torch, h, act, res, secs_l, n, masks = self.torch, self.h, self.act, self.res, self.secs_l, self.n, self.masks
+        names_l, fits = [], []
         with torch.cuda.stream(self.side):
             for i, s in enumerate(act):
                 names_l.append([s._names_from_mask(int(m)) for m in masks[i][:len(secs_l[i])]])
@@ -271,12 +326,13 @@ class _Group:
                 s._state.write(2, P)
             for s in act:
                 s.store_score_distribution()
+        vres, vframes, ev, cand_l, offs, _ = self.vq
         self.pending = (vres, vframes, ev, cand_l, offs, names_l)
 
     def end(self):
         """Wait for the verification batch; the sequential ``remaining_targets`` replay and its score overwrites."""
         if self.pending is None:
-            if self.spec is not None:             # (defensive: a speculation always follows a middle())
+            if self.spec is not None:             # (defensive: a speculation always follows an update())
                 self._drop_speculation()
             return
         torch = self.torch
@@ -296,11 +352,14 @@ class _Group:
         for s in act:
             s.iterations += 1
         self.res = self.grids = None
+        self.vq = None
         if self.spec is not None:
             # the speculation was made with this iteration's budget already spent, so "still active" is the same test it used
             still = [s for s in self.spec[0] if s.remaining_targets]
             if len(still) != len(self.spec[0]):
                 self._drop_speculation()
+            elif self.ahead is not None and any(list(s.remaining_targets) != snap for s, snap in zip(self.spec[0], self.ahead[1][5])):
+                self._drop_ahead()                # a target was found and the search goes on: the next batch has fewer candidates
         self.act = self._active() if self.spec is None else list(self.spec[0])
 
     def finish(self):
@@ -363,19 +422,34 @@ def search_lockstep_groups(groups: Sequence[Sequence[TStarSearcher]]) -> List[Li
 def search_solo(searcher: TStarSearcher) -> Tuple[np.ndarray, list]:
     """``TStarSearcher.search()`` of ONE searcher on the fast path: the same statements in the same order as the sequential loop
     (interface_searcher.py:444-491 of the reference), cut at the two points where the host waits for the detector, with the state
-    kernels on the side stream and the next iteration's grid forward queued speculatively behind each verification batch
-    (``_Group.speculate``).  The searcher keeps its own query-set slot 0 and its public ``sample_frames`` hook."""
+    kernels on the side stream, the next iteration's grid forward queued speculatively BESIDE each verification batch (its own stream
+    and detector workspace: ``_Group.speculate``) and, round 6, the next verification batch queued behind the running one as soon as
+    that forward is back (``_Group.verify_ahead``).  The searcher keeps its own query-set slot 0 and its public ``sample_frames`` hook.
+
+    What the detector sees: verification batch t | verification batch t + 1 | ... back to back on the caller's stream, grid forward
+    t + 1 beside batch t on the auxiliary stream; what the host does meanwhile: fit(t) -> samples(t + 1) -> [wait for grid forward
+    t + 1] -> queue batch t + 1 -> results of batch t, replay.  Every state-changing statement keeps its place in the reference's
+    order: write-back / spread / P of iteration t + 1 come after the score overwrites of verification t."""
     import torch
     g = _Group([searcher], 0, torch)
     g.solo = True
     searcher._slot = 0
     g.install()
-    while g.act:
-        g.begin()
-        g.middle()
+    if not g.act:
+        return g.finish()[0]
+    g.begin()
+    g.verify_launch()
+    while True:
+        g.update()                     # write-back, fit, P, histories of iteration t (its verification batch is running)
         if _SPECULATE:
-            g.speculate()
-        g.end()
+            g.speculate()              # samples and grid forward of iteration t + 1, beside the verification batch
+            if _AHEAD and not g.verification_done():
+                g.verify_ahead()       # ... and its verification batch behind the one in flight
+        g.end()                        # verification results of iteration t, replay
+        if not g.act:
+            break
+        g.begin()
+        g.verify_launch()
     return g.finish()[0]
 
 
