@@ -353,11 +353,6 @@ int tstar_prof_read_totals(int category, long long* launches_all, double* flops_
 /* trace markers: enqueue an empty kernel named prof_mark_begin_kernel (which = 0) / prof_mark_end_kernel (1) on `stream`,
  * so that a rocprofv3 kernel trace can be cut to the bracketed region on the GPU's own timeline */
 int tstar_prof_mark(int which, void* stream);
-/* Round 6.  A HIP stream of the lowest priority the device offers, for work that should only fill what the caller's stream leaves idle
- * (the speculative next-grid forward on workspace lane 1 -- tstar_owl_score_lane); a helper for hosts whose own stream API cannot ask
- * for a priority below the default.  The library still enqueues only on streams it is handed. */
-int tstar_stream_create_low_priority(void** out_stream, int* out_priority);
-int tstar_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

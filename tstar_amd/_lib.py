@@ -84,8 +84,6 @@ SIGNATURES = {
     "tstar_prof_read_bytes": (_i, [_i, _vp]),
     "tstar_prof_read_totals": (_i, [_i, _vp, _vp]),
     "tstar_prof_mark": (_i, [_i, _vp]),
-    "tstar_stream_create_low_priority": (_i, [C.POINTER(_vp), C.POINTER(_i)]),
-    "tstar_stream_destroy": (_i, [_vp]),
 }
 
 _lib = None

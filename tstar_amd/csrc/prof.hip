@@ -95,24 +95,6 @@ int tstar_prof_read_bytes(int category, double* total_bytes) {
     *total_bytes = g_cat[category].bytes;
     return TSTAR_OK;
 }
-// A stream of the LOWEST priority the device offers (hipStreamNonBlocking), for work that should only fill what the caller's own stream
-// leaves idle: the searcher's speculative next-grid forward beside the verification batch (tstar_amd/lockstep.py).  The library itself
-// still enqueues only on the streams it is handed; this is a helper for hosts whose stream API cannot ask for a priority below the default
-// (torch.cuda.Stream cannot).  *out_priority receives the priority the stream got (== the default's when the device has one level).
-int tstar_stream_create_low_priority(void** out_stream, int* out_priority) {
-    TSTAR_REQUIRE(out_stream, "tstar_stream_create_low_priority: null argument");
-    int least = 0, greatest = 0;
-    TSTAR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));      // numerically: least >= greatest
-    hipStream_t s = nullptr;
-    TSTAR_HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
-    *out_stream = s;
-    if (out_priority) *out_priority = least;
-    return TSTAR_OK;
-}
-int tstar_stream_destroy(void* stream) {
-    if (stream) TSTAR_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
-    return TSTAR_OK;
-}
 int tstar_prof_mark(int which, void* stream) {
     TSTAR_REQUIRE(which == 0 || which == 1, "tstar_prof_mark: which must be 0 (begin) or 1 (end)");
     if (which == 0) hipLaunchKernelGGL(prof_mark_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);

@@ -61,19 +61,9 @@ def _accepts_lane(fn) -> bool:
 
 
 def _aux_stream(torch):
-    """The stream of the speculative forwards: of the LOWEST priority the device offers (created through the library:
-    torch.cuda.Stream cannot ask for less than the default), so that they fill what the verification batch leaves idle instead of
-    sharing the chip with it evenly.  TSTAR_AUX_PRIORITY=default: a plain torch stream (same-session A/Bs)."""
     d = torch.cuda.current_device()
     if d not in _AUX:
-        if os.environ.get("TSTAR_AUX_PRIORITY", "low") == "low":
-            import ctypes as C
-            from . import _lib
-            p, pr = C.c_void_p(), C.c_int(0)
-            _lib.check(_lib.load().tstar_stream_create_low_priority(C.byref(p), C.byref(pr)), "tstar_stream_create_low_priority")
-            _AUX[d] = torch.cuda.ExternalStream(p.value, device=d)       # lives as long as the process
-        else:
-            _AUX[d] = torch.cuda.Stream(device=d)
+        _AUX[d] = torch.cuda.Stream(device=d)
     return _AUX[d]
 
 
