@@ -82,3 +82,41 @@ def test_checkpoint_without_vocabulary_refuses_made_up_ids(ckpt, tmp_path):
     h = OWLInterface(model_name_or_path=str(bare), max_batch=1)
     with pytest.raises(RuntimeError, match="no CLIP tokenizer files"):
         h.reparameterize_object_list(["couch"], [])
+
+
+def test_real_owlvit_base_patch32_when_a_local_snapshot_exists():
+    """Opt-in pin of row D1 on the REAL checkpoint (review item 8 of round 5): when this box holds an HF-cache snapshot (or
+    TSTAR_REAL_OWLVIT points at a checkpoint directory) of ``google/owlvit-base-patch32`` -- nothing can be downloaded here, so the
+    test SKIPS otherwise -- the heuristic is built exactly as the reference builds it (``initialize_heuristic("owl-vit")``, no
+    keywords) and compared with HF transformers' own forward on the same files: text embeddings, dense scores within the 1e-3
+    contract, kept boxes.  Both arithmetic modes."""
+    import hf_checkpoint_util as H
+    from tstar_amd import weights as W
+    from tstar_amd.interface_heuristic import initialize_heuristic
+    from tstar_amd.video import synthetic_frames_numpy
+    name = os.environ.get("TSTAR_REAL_OWLVIT") or "google/owlvit-base-patch32"
+    ck = W.find_pretrained(name)
+    if ck is None:
+        pytest.skip("no local snapshot of google/owlvit-base-patch32 (offline image); set TSTAR_REAL_OWLVIT=<checkpoint dir> or fill the HF cache")
+    from transformers import CLIPTokenizer, OwlViTForObjectDetection
+    d = os.path.dirname(ck)
+    m = OwlViTForObjectDetection.from_pretrained(d, local_files_only=True).eval()
+    tok = CLIPTokenizer.from_pretrained(d, local_files_only=True)
+    names = ["couch", "tv", "remote control", " "]
+    from oracle import resize_ref as R
+    img = R.cv_bilinear_resize(synthetic_frames_numpy([3], 40, 360, 640, seed=5)[0], 800, 380)
+    ref = H.hf_detect(m, tok, img, names)
+    for mode in ("f32", "f32x3"):
+        if name == "google/owlvit-base-patch32":
+            h = initialize_heuristic("owl-vit", weights_dtype=mode)
+        else:
+            from tstar_amd.interface_heuristic import OWLInterface
+            h = OWLInterface(model_name_or_path=name, weights_dtype=mode)
+        assert h.weights_source == ck and not h.allow_standin_tokenizer
+        h.reparameterize_object_list(names[:1], names[1:-1])
+        assert np.abs(h.scorer.get_query_embeds() - ref["text_embeds"]).max() < 1e-5
+        r = h.scorer.score(torch.from_numpy(img).cuda().unsqueeze(0), 4, 4)
+        assert float(np.abs(r.scores[0].cpu().numpy() - ref["dense_scores"]).max()) < 1e-3, mode
+        det = h.inference_detector([img])[0]
+        assert len(det) == len(ref["scores"]) and np.abs(det.confidence - ref["scores"]).max() < 1e-3
+        del h
