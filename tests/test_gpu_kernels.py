@@ -133,7 +133,10 @@ def test_gemm_bf16_weights_two_term(lib, M, N, K, act, res):
     Every tile choice -- tile_cfg 0..3 (128x128 / 64x128 / 64x64 / hybrid), 4 = the 128x256 tile on every full 128-row panel
     (64x128 tiles on the ragged rest), 5 = wide tile forbidden, -1 = the launcher's choice (whole waves of wide tiles from 512
     of them on: the last three shapes) -- must agree with the float64 product of the same operands, and with each other bit
-    for bit (same K order, same products).  The float64 reference is formed once per shape."""
+    for bit (same K order, same products).  The float64 reference is formed once per shape.
+    Round 6: 6 = the wide tile with its weight fragments streamed global -> VGPR from the fragment-packed plane (gemm_tile_w2v, what the
+    launcher picks on its own for N = 768 from one wave of wide tiles on: shapes four and six, with their residual epilogues) -- the
+    same bits again, on every shape whose N is a multiple of 256 (K = 64: two K tiles; ragged M; quick-GELU / GELU epilogues)."""
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
     A[::7] *= 1e-3                                             # wide dynamic range across rows
@@ -151,7 +154,7 @@ def test_gemm_bf16_weights_two_term(lib, M, N, K, act, res):
     dR = R.cuda() if res else None
     st = torch.cuda.current_stream().cuda_stream
     outs = {}
-    for cfg in (5, -1, 0, 1, 2, 3, 4):
+    for cfg in (5, -1, 0, 1, 2, 3, 4) + ((6,) if N % 256 == 0 and M >= 128 else ()):
         dC = torch.full((M, N), float("nan"), device="cuda")
         _check(lib.tstar_gemm_bf16w2(dA.data_ptr(), dW.data_ptr(), dC.data_ptr(), db.data_ptr(), dR.data_ptr() if res else None, M, N, K, 0,
                                      cfg, st))
@@ -166,10 +169,13 @@ def test_gemm_bf16_weights_two_term(lib, M, N, K, act, res):
     if act:
         r32 = ref.to(torch.float32)
         want = r32 * torch.sigmoid(1.702 * r32) if act == 1 else F.gelu(r32)
-        for cfg in (-1, 4):
+        first = None
+        for cfg in (-1, 4) + ((6,) if N % 256 == 0 and M >= 128 else ()):
             dC2 = torch.empty((M, N), device="cuda")
             _check(lib.tstar_gemm_bf16w2(dA.data_ptr(), dW.data_ptr(), dC2.data_ptr(), db.data_ptr(), None, M, N, K, act, cfg, st))
             assert (dC2.cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+            first = dC2 if first is None else first
+            assert torch.equal(dC2, first), cfg
 
 
 @pytest.mark.parametrize("M,N,K,act,res", [(577, 768, 3072, 0, False), (130, 256, 64, 1, False), (1154, 512, 768, 2, False),

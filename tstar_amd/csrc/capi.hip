@@ -112,6 +112,12 @@ struct tstar_owl {
     int weights_mode = TSTAR_WEIGHTS_F32;
     std::unordered_map<const float*, __bf16*> wb;
     std::unordered_map<const float*, void*> wp;
+    std::unordered_map<const float*, void*> wq;          // two-term mode, the N = 768 matrices: the bf16 plane once more in MFMA-fragment order
+    const void* w2_of(const float* w) const {
+        if (weights_mode != TSTAR_WEIGHTS_BF16) return nullptr;
+        auto it = wq.find(w);
+        return it == wq.end() ? nullptr : it->second;
+    }
     const __bf16* bf16_of(const float* w) const {
         if (weights_mode != TSTAR_WEIGHTS_BF16 && weights_mode != TSTAR_WEIGHTS_BF16_EXACT) return nullptr;
         auto it = wb.find(w);
@@ -178,7 +184,7 @@ static int get_table(tstar_owl* h, int in_size, ResampleTable** out, hipStream_t
 static GemmArgs mk_gemm(const tstar_owl* h, const float* A, const float* W, float* C, const float* bias, const float* res,
                         int M, int N, int K, int lda, int ldc, int act) {
     GemmArgs g{};
-    g.A = A; g.W = W; g.Wb = h ? h->bf16_of(W) : nullptr; g.Wp = h ? h->packed_of(W) : nullptr; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
+    g.A = A; g.W = W; g.Wb = h ? h->bf16_of(W) : nullptr; g.Wp = h ? h->packed_of(W) : nullptr; g.Wq = h ? h->w2_of(W) : nullptr; g.C = C; g.bias = bias; g.res = res; g.pos = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.act = act; g.patch_np = 0; g.tile_cfg = -1; g.m_split = 0;
     g.a_terms = h && h->weights_mode == TSTAR_WEIGHTS_BF16 ? 2 : 0;      // bf16 weights: two-term activations unless the exact mode is asked for
     return g;
@@ -281,6 +287,13 @@ static int make_bf16_copies(tstar_owl* h, int mode) {
             TSTAR_HIP_CHECK(hipMalloc(&p, n * sizeof(__bf16)));
             h->wb[m.w] = p;
             rc = convert_f32_to_bf16(m.w, p, nullptr, n, 0);
+            static const bool w2v_off = getenv("TSTAR_W2V_OFF") != nullptr;           // same-session A/Bs: every layer on the LDS tile
+            if (!rc && mode == TSTAR_WEIGHTS_BF16 && m.n == 768 && m.k % 32 == 0 && !w2v_off) {       // per-shape dispatch (gemm_f32.hip launch_mode)
+                void* q = nullptr;
+                TSTAR_HIP_CHECK(hipMalloc(&q, n * sizeof(__bf16)));
+                h->wq[m.w] = q;
+                rc = pack_weights_w2(p, q, m.n, m.k, 0);
+            }
         }
         if (rc) return rc;
     }
@@ -354,6 +367,7 @@ int tstar_owl_destroy(tstar_owl* h) {
     for (auto& kv : h->tabs) free_table(&kv.second);
     for (auto& kv : h->wb) if (kv.second) (void)hipFree(kv.second);
     for (auto& kv : h->wp) if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : h->wq) if (kv.second) (void)hipFree(kv.second);
     delete h;
     return TSTAR_OK;
 }
@@ -663,15 +677,22 @@ static int gemm_converted(const char* fn, int a_terms, const float* d_A, const f
     __bf16* wb = nullptr;
     TSTAR_HIP_CHECK(hipMalloc(&wb, (size_t)N * K * sizeof(__bf16)));
     int rc = convert_f32_to_bf16(d_W, wb, nullptr, (size_t)N * K, s);
+    void* wq = nullptr;
+    if (!rc && a_terms == 2 && N % 256 == 0 && K % 32 == 0) {       // the fragment-packed plane of the two-term mode's VGPR-weight tile (tile_cfg 6, or N = 768)
+        TSTAR_HIP_CHECK(hipMalloc(&wq, (size_t)N * K * sizeof(__bf16)));
+        rc = pack_weights_w2(wb, wq, N, K, s);
+    }
     if (!rc) {
         GemmArgs g = mk_gemm(nullptr, d_A, d_W, d_C, d_bias, d_residual, M, N, K, K, N, act);
         g.Wb = wb;
+        g.Wq = wq;
         g.a_terms = a_terms;
         g.tile_cfg = tile_cfg;
         rc = gemm_f32(g, s);
     }
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(wb);
+    if (wq) (void)hipFree(wq);
     if (!rc && e != hipSuccess) { set_error(std::string(fn) + ": " + hipGetErrorString(e)); rc = TSTAR_ERR_HIP; }
     return rc;
 }

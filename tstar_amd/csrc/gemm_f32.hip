@@ -709,6 +709,184 @@ int pack_weights_x3(const float* W, void* Wp, int N, int K, hipStream_t s) {
     return TSTAR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-term tile with the weight fragments global -> VGPR (round 6; lab: tools/lab/x3_lab.hip `gemm_w2_v2`, profiles/r05_two_term_v2_lab.log).
+// The same arithmetic as gemm_tile_bf16w<.., WMODE 3>: bf16 weights (one exact plane), activations split while staged into
+// a_hi = bf16(a), a_lo = bf16(a - a_hi), and per K = 16 step and accumulator  C += a_lo w, then C += a_hi w  -- same products, same order,
+// same bits -- on the per-wave software pipeline of gemm_tile_x3: the weight plane packed in MFMA-fragment order
+// ([n-tile of 32][k / 16][lane][8 bf16]: a wave's B operand of one step is ONE contiguous 1-KB buffer load), fragments in two slot sets
+// re-loaded two steps ahead right after their last product, LDS carries only the two activation planes (32 KB per 128-row block), the split
+// of the next K tile in pieces between the MFMA groups of a tile's first step, ONE barrier per K tile between its two steps.
+// Measured against the LDS tile on the batch shapes: +12 ... +20 % where N = 768 (out-proj 396 -> 467-480, fc2 496 -> 555-568 TFLOP/s
+// algorithmic), +-3 % on the wide layers (4 MFMAs per loaded KB put ~48 B/clk on the 64 B/clk vector-memory path) -- so the launcher
+// uses it for N = 768 only (launch_mode).
+template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+__device__ __forceinline__ void gemm_tile_w2v(const GemmArgs& g, const int m0, const int n0, float* smem_f) {
+    constexpr int TM = CF::TM, TN = CF::TN, BM = CF::BM;
+    static_assert(TN % 2 == 0, "column tiles go in pairs");
+    constexpr int A_T = BM * 64, BUF = 2 * A_T;                           // bytes: one plane, one buffer (two planes)
+    constexpr int NA = BM / 32;
+    char* smem = reinterpret_cast<char*>(smem_f);
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int c4 = t & 7, r0 = t >> 3;
+    unsigned aoff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int ar = m0 + r0 + 32 * i;
+        ar = ar < g.M ? ar : g.M - 1;
+        aoff[i] = (unsigned)(ar - m0) * (unsigned)g.lda * 4u + c4 * 16;
+    }
+    const int nsteps = g.K / 16, nk = g.K / BK;
+    const char* wrow = static_cast<const char*>(g.Wq) + (size_t)((n0 >> 5) + wn * TN) * nsteps * 1024;
+    const __amdgpu_buffer_rsrc_t ra_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)m0 * g.lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wrow), 0, 0x7fffffff, 0x00020000);
+    const int voff = lane * 16;
+    const int rd0 = (wm * TM * 32 + l31) * 64 + ((h ^ ((l31 >> 2) & 3)) << 4);
+    const int rd1 = rd0 ^ 32;
+    const int wr0 = r0 * 64 + (((c4 >> 1) ^ ((r0 >> 2) & 3)) << 4) + (c4 & 1) * 8;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[NA];
+    u32x4 w[2][TN];                                                       // w[set][j]: step parity -> set
+    bf16x8 a0[2][TM], a1[TM];                                             // a0 = a_hi (double-buffered), a1 = a_lo
+    unsigned sp[2][2];
+
+    auto gload_a = [&](int kt) __attribute__((always_inline)) {
+        kt = kt < nk ? kt : nk - 1;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, (int)aoff[i], kt * (BK * 4), 0));
+    };
+    auto wload = [&](auto SET, auto J, int gs) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value, j = decltype(J)::value;
+        gs = gs < nsteps ? gs : nsteps - 1;
+        w[st][j] = __builtin_amdgcn_raw_buffer_load_b128(rw_rsrc, voff, (j * nsteps + gs) * 1024, 0);
+    };
+    auto rd_a = [&](const char* base, int off, int plane, int i) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8*>(base + off + plane * A_T + i * 2048);
+    };
+    // hi = bf16(x), lo = bf16(x - hi): the arithmetic of split4_bf16x2 on one pair
+    auto split_pair = [&](float x0, float x1, unsigned (&o)[2]) __attribute__((always_inline)) {
+        f32x2 x; x[0] = x0; x[1] = x1;
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+        o[0] = hb;
+        f32x2 r; r[0] = x0 - __uint_as_float(hb << 16); r[1] = x1 - __uint_as_float(hb & 0xFFFF0000u);
+        o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    };
+    auto stage_piece = [&](auto P, char* wbase) __attribute__((always_inline)) {
+        constexpr int p = decltype(P)::value, i = p >> 1, hf = p & 1;
+        split_pair(ra[i][2 * hf], ra[i][2 * hf + 1], sp[hf]);
+        if constexpr (hf == 1) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                u32x2 v; v[0] = sp[0][k]; v[1] = sp[1][k];
+                *reinterpret_cast<u32x2*>(wbase + wr0 + k * A_T + i * 2048) = v;
+            }
+        }
+    };
+    auto mf = [&](const bf16x8& a, const u32x4& b, f32x16& c) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    auto step = [&](auto SS, const char* rbase, int roff, char* wbase, int gs, int ktload) __attribute__((always_inline)) {
+        constexpr int S = decltype(SS)::value;                            // step inside the tile = weight slot set = a0 set
+        constexpr int NPIECE = NA * 2, GP = TN / 2, NG = 2 * GP, PPG = (NPIECE + 1 + NG - 1) / NG;
+        auto after_group = [&](auto G) __attribute__((always_inline)) {
+            constexpr int gi = decltype(G)::value;
+            if constexpr (S == 0) {
+                [&]<int... Q>(std::integer_sequence<int, Q...>) __attribute__((always_inline)) {
+                    ([&] {
+                        constexpr int p = gi * PPG + Q;
+                        if constexpr (p < NPIECE) stage_piece(std::integral_constant<int, p>{}, wbase);
+                        if constexpr (p == NPIECE) gload_a(ktload);
+                    }(), ...);
+                }(std::make_integer_sequence<int, PPG>{});
+            }
+            if constexpr (gi == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[S ^ 1][i] = rd_a(rbase, roff, 0, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        [&]<int... JP>(std::integer_sequence<int, JP...>) __attribute__((always_inline)) {
+            ([&] {
+                constexpr int j0 = 2 * JP;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a1[i], w[S][j0 + jj], acc[i][j0 + jj]);          // a_lo w first
+                after_group(std::integral_constant<int, 2 * JP + 0>{});
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mf(a0[S][i], w[S][j0 + jj], acc[i][j0 + jj]);       // then a_hi w
+                wload(std::integral_constant<int, S>{}, std::integral_constant<int, j0>{}, gs + 2);
+                wload(std::integral_constant<int, S>{}, std::integral_constant<int, j0 + 1>{}, gs + 2);
+                if constexpr (JP == GP - 1) {                             // a_lo's last product of the step has issued
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a1[i] = rd_a(rbase, roff, 1, i);
+                }
+                after_group(std::integral_constant<int, 2 * JP + 1>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, GP>{});
+    };
+
+    gload_a(0);
+    [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
+        ((wload(std::integral_constant<int, 0>{}, std::integral_constant<int, J>{}, 0),
+          wload(std::integral_constant<int, 1>{}, std::integral_constant<int, J>{}, 1)), ...);
+    }(std::make_integer_sequence<int, TN>{});
+    [&]<int... P>(std::integer_sequence<int, P...>) __attribute__((always_inline)) {
+        (stage_piece(std::integral_constant<int, P>{}, smem), ...);
+    }(std::make_integer_sequence<int, NA * 2>{});
+    gload_a(1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { a0[0][i] = rd_a(smem, rd0, 0, i); a1[i] = rd_a(smem, rd0, 1, i); }
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * BUF;
+        char* nxt = smem + ((kt + 1) & 1) * BUF;
+        step(std::integral_constant<int, 0>{}, cur, rd1, nxt, 2 * kt, kt + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        step(std::integral_constant<int, 1>{}, nxt, rd0, nxt, 2 * kt + 1, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    gemm_epilogue<CF, ACT, HAS_BIAS, HAS_RES, PATCH>(g, acc, m0, n0, wm, wn, l31, h);
+}
+
+// Wq[n-tile][ks][lane][e] = bf16(W[32 n-tile + (lane & 31)][16 ks + 8 (lane >> 5) + e]) from the bfloat16 copy Wb [N, K]: one thread per
+// (row, 8-k chunk), one 16-byte load, one 16-byte store
+__global__ __launch_bounds__(256) void pack_w2_kernel(const __bf16* __restrict__ Wb, char* __restrict__ Wq, int N, int K) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int kc = K / 8;
+    if (gid >= (size_t)N * kc) return;
+    const int n = (int)(gid / kc), c = (int)(gid % kc);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(Wb + (size_t)n * K + c * 8);
+    const int ks = c >> 1, hh = c & 1;
+    *reinterpret_cast<u32x4*>(Wq + (((size_t)(n >> 5) * (K / 16) + ks) * 64 + hh * 32 + (n & 31)) * 16) = v;
+}
+
+int pack_weights_w2(const __bf16* Wb, void* Wq, int N, int K, hipStream_t s) {
+    TSTAR_REQUIRE(N % 32 == 0 && K % 16 == 0, "pack_weights_w2: N must be a multiple of 32, K of 16");
+    const size_t n = (size_t)N * (K / 8);
+    hipLaunchKernelGGL(pack_w2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wb, static_cast<char*>(Wq), N, K);
+    TSTAR_HIP_CHECK(hipGetLastError());
+    return TSTAR_OK;
+}
+
 // One output tile of shape CF at (m0, n0).  `smem` is the block's dynamic LDS.
 template <class CF, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int m0, const int n0, float* smem) {
@@ -841,7 +1019,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_hybrid_kernel(GemmArgs g) {
 
 // Wide hybrid launch of the two-term bf16-weight mode (WMODE 3) and of the f32x3 mode (WMODE 4): rows [0, m_split) in 128x256 tiles (whole waves of the 512
 // resident slots), the remaining rows in 64x128 tiles that arrive last and fill the tail.
-template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+// VW (two-term mode only): the wide tiles take their weight fragments global -> VGPR from the fragment-packed plane g.Wq (gemm_tile_w2v)
+template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH, bool VW = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w2_wide_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ntw = g.N / 256;
@@ -851,6 +1030,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w2_wide_kernel(GemmArgs g) {
         int mi, ni;
         tile_mn(tile, g.m_split / 128, ntw, g.group_m, mi, ni);
         if constexpr (WMODE == 4) gemm_tile_x3<Cfg128W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * 128, ni * 256, smem);
+        else if constexpr (VW) gemm_tile_w2v<Cfg128W, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * 128, ni * 256, smem);
         else gemm_tile_bf16w<Cfg128W, 3, ACT, HAS_BIAS, HAS_RES, PATCH>(g, mi * 128, ni * 256, smem);
     } else {
         const int nt = g.N / 128;
@@ -905,10 +1085,10 @@ static int launch_hybrid(const GemmArgs& g, hipStream_t stream) {
     return TSTAR_OK;
 }
 
-template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH>
+template <int WMODE, int ACT, bool HAS_BIAS, bool HAS_RES, bool PATCH, bool VW = false>
 static int launch_wide(const GemmArgs& g, hipStream_t stream) {
-    constexpr int lds = lds_bytes<WMODE>(128, 256);
-    auto kern = gemm_bf16w2_wide_kernel<WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>;
+    constexpr int lds = lds_bytes<WMODE>(128, 256);       // (VW: the wide tile needs 32 KB, the 64x128 tail tile of the same kernel this much)
+    auto kern = gemm_bf16w2_wide_kernel<WMODE, ACT, HAS_BIAS, HAS_RES, PATCH, VW>;
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     const int nwg = (g.m_split / 128) * (g.N / 256) + cdiv(g.M - g.m_split, 64) * (g.N / 128);
     const bool prof = prof_enabled();
@@ -968,11 +1148,11 @@ static int launch_mode(const GemmArgs& g, hipStream_t stream) {
         // tile's rate: three rounds of them cost more than one round of wide tiles -- tools/bench_gemm_bf16.py: out-proj
         // at B = 64, 864 wide tiles: 410 all wide vs 384 with a narrow tail), else they and the ragged rows go out as
         // 64x128 tiles that fill the tail (tile_cfg 4 forces every full 128-row panel wide; 5 forces the wide tile OFF)
-        if (g.N % 256 == 0 && forced != 5 && (forced == -1 || forced == 4)) {
+        if (g.N % 256 == 0 && forced != 5 && (forced == -1 || forced == 4 || forced == 6)) {
             const int ntw = g.N / 256, mt = g.M / 128;       // full 128-row panels only
             const long long bw = (long long)mt * ntw;
             int big = 0;
-            if (forced == 4) big = mt;
+            if (forced == 4 || forced == 6) big = mt;
             else if (bw >= 512) big = (bw % 512) > 256 ? mt : (int)(((bw / 512) * 512) / ntw);
             // f32x3, under one wave of wide tiles (tools/sweep_x3_cfg.py, profiles/r05_x3_cfg_sweep.log): the wide tile still wins when its
             // blocks nearly fill the 512 slots (>= 400: fc1 at B = 8 195 -> 216, qkv at B = 10 190 -> 212 TFLOP/s) or when every block gets
@@ -982,11 +1162,19 @@ static int launch_mode(const GemmArgs& g, hipStream_t stream) {
             if (big > 0 && fits32) {
                 GemmArgs h = g;
                 h.m_split = big * 128;
+                if constexpr (WMODE == 3) {
+                    // round 6, per-shape dispatch: with a fragment-packed plane at hand the wide tiles of the N = 768 layers (out-proj, fc2,
+                    // patch embedding, box head) stream their weights global -> VGPR (+12 ... +20 % there; +-3 % on the wide layers, which
+                    // keep the LDS tile).  Same bits either way.  tile_cfg 6 forces this tile on every full panel of any N (tests).
+                    if (g.Wq && (forced == 6 || (forced == -1 && g.N == 768))) return launch_wide<3, ACT, HAS_BIAS, HAS_RES, PATCH, true>(h, stream);
+                }
+                TSTAR_REQUIRE(forced != 6, "gemm_f32: tile_cfg 6 needs the two-term mode with a fragment-packed weight plane (Wq)");
                 return launch_wide<WMODE, ACT, HAS_BIAS, HAS_RES, PATCH>(h, stream);
             }
         }
     }
     int m_split = 0;
+    TSTAR_REQUIRE(forced != 6, "gemm_f32: tile_cfg 6 (two-term wide tile, weights global -> VGPR) needs N % 256 == 0, at least one full 128-row panel and a packed plane");
     int cfg = (forced >= 0 && forced <= 3) || forced >= 16 ? forced : pick_cfg(g.M, g.N, &m_split);
     if (forced == 3) {                                       // forced hybrid: half of the row tiles big
         m_split = (cdiv(g.M, 128) / 2) * 128;
@@ -1027,7 +1215,7 @@ int gemm_f32(const GemmArgs& g0, hipStream_t stream) {
     TSTAR_REQUIRE(g.N % 128 == 0, "gemm_f32: N must be a multiple of 128");
     TSTAR_REQUIRE(g.K % BK == 0, "gemm_f32: K must be a multiple of 32");
     TSTAR_REQUIRE(g.lda % 4 == 0 && g.K % 4 == 0, "gemm_f32: rows must be 16-byte aligned");
-    TSTAR_REQUIRE((g.tile_cfg >= -1 && g.tile_cfg <= 5) || g.tile_cfg >= 16, "gemm_f32: tile_cfg must be -1..5 (or 16 + big row tiles)");
+    TSTAR_REQUIRE((g.tile_cfg >= -1 && g.tile_cfg <= 6) || g.tile_cfg >= 16, "gemm_f32: tile_cfg must be -1..6 (or 16 + big row tiles)");
     const bool bias = g.bias != nullptr, res = g.res != nullptr, patch = g.pos != nullptr;
     if (patch) {
         TSTAR_REQUIRE(!bias && !res && g.act == ACT_NONE && g.patch_np > 0, "gemm_f32: patch epilogue takes no bias/res/act");

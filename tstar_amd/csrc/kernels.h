@@ -11,6 +11,7 @@ struct GemmArgs {
     const float* W;      // [N, K] row-major (nn.Linear layout)
     const __bf16* Wb;    // optional bfloat16 copy of W: selects the bf16-weight tile (exact split of A)
     const void* Wp;      // optional fragment-packed three-plane copy of W (pack_weights_x3): selects the f32x3 tile
+    const void* Wq;      // optional fragment-packed copy of Wb (pack_weights_w2): the two-term mode's wide tile may stream its weights global -> VGPR
     float* C;            // [*, ldc]
     const float* bias;   // [N] or null
     const float* res;    // residual, same layout as C, or null (may alias C)
@@ -18,7 +19,7 @@ struct GemmArgs {
     int M, N, K, lda, ldc;
     int act;             // ACT_*
     int patch_np;        // patches per image (576) for the patch-embed epilogue
-    int tile_cfg;        // -1 auto; 0 = 128x128, 1 = 64x128, 2 = 64x64 block tile, 3 = hybrid 128x128 + 64x128 tail (half/half); 16 + n = hybrid with n big row tiles (diagnostic)
+    int tile_cfg;        // (4 / 5: wide tile forced on / off; 6: the two-term wide tile with weights global -> VGPR forced)  -1 auto; 0 = 128x128, 1 = 64x128, 2 = 64x64 block tile, 3 = hybrid 128x128 + 64x128 tail (half/half); 16 + n = hybrid with n big row tiles (diagnostic)
     int m_split;         // hybrid launch: rows [0, m_split) use 128-row tiles (set by the launcher)
     int group_m;         // row panels per super-panel of the tile order (gemm_f32.hip tile_mn); 0 = the library's default
     int a_terms;         // bf16-weight tile (Wb set): 2 = activations as two round-to-nearest bf16 terms (2 MFMA
@@ -28,6 +29,9 @@ int gemm_f32(const GemmArgs& g, hipStream_t stream);
 
 // Wb[i] = bfloat16(W[i]) (round to nearest even); n elements.  With Wlo != null also Wlo[i] = bfloat16(W[i] - Wb[i]).
 int convert_f32_to_bf16(const float* W, __bf16* Wb, __bf16* Wlo, size_t n, hipStream_t s);
+
+// two-term mode: Wb [N, K] bf16 -> the same values in MFMA-fragment order, 2 * N * K bytes (gemm_f32.hip)
+int pack_weights_w2(const __bf16* Wb, void* Wq, int N, int K, hipStream_t s);
 
 // f32x3 mode: W [N, K] f32 -> three exact bf16 planes in MFMA-fragment order, 6 * N * K bytes (gemm_f32.hip)
 int pack_weights_x3(const float* W, void* Wp, int N, int K, hipStream_t s);
