@@ -208,13 +208,14 @@ def grid4_record(heuristic, store, nframes, k):
             "solo_sec_per_video": t_solo, "solo_frames_per_s": solo[0][0].frames_scored / t_solo,
             "grid_calls_per_video": sum(s_.iterations for s_, _ in grp) / nv,
             "verify_calls_per_video": sum(s_.detector_calls - s_.iterations for s_, _ in grp) / nv,
-            "solo_bound": "GPU kernels are ~0.59 s of a 0.58 s search without the tracer / 81 % of the traced window (profiles/r05_solo_grid4_gaps.txt; "
-                          "under the tracer the idle is the host FITPACK fit of the LATE iterations, ~800 knots, outlasting the verification "
-                          "forward it overlaps); the kernels run at small batch: a B = 1 grid forward (M = 577, 2.06 ms: 456-1824 wave tiles for "
-                          "1024 SIMDs) and a B ~ 10 verification forward per iteration, 63 iterations, 670 detector images at ~0.9 ms each against "
-                          "0.55 ms in the lock-step bench.  The next iteration's grid forward is queued speculatively behind each verification batch "
-                          "(tstar_amd.lockstep._Group.speculate), the 64x64 tile keeps the weight fragments of four K = 16 steps in flight "
-                          "(csrc/gemm_f32.hip); split-K for the M = 577 launches would change bits with the batch size and is not used"}
+            "solo_bound": "kernel throughput at small batch: per iteration a B ~ 9.5 verification forward (M ~ 5500: 146-186 TFLOP/s algorithmic on its GEMMs, "
+                          "~0.62 ms an image against 0.55 ms in the lock-step bench) and a B = 1 grid forward (M = 577: 120-456 wave tiles per GEMM for 1024 SIMDs, "
+                          "2.06 ms alone), 63 iterations, 670 detector images.  Round 5 ran them back to back on one stream (593 ms of kernels in a 580 ms "
+                          "search); since round 6 the NEXT iteration's grid forward runs BESIDE the verification batch on its own stream and detector workspace "
+                          "(tstar_owl_score_lane) and the next verification batch is queued behind the running one before its results are read "
+                          "(tstar_amd/lockstep.py: speculate / verify_ahead): 0.571 -> 0.510 s same-box (profiles/r06_solo_grid4_ab.md).  The verification "
+                          "batch's own kernels already fill most of the 512 block slots, so the small forward mostly shares the chip with them; what is left "
+                          "is tile efficiency at M = 577 / M ~ 5500, which only split-K would change -- and split-K makes result bits depend on the batch size"}
 
 
 def drop_in_record(store, k):
@@ -861,40 +862,50 @@ def main():
                   "search_nframes": args.search_nframes, "workload_kind": workload, "n_gpus": world, "concurrency": conc}
     alg_bytes_run = by.value / max(n_l.value, 1)
 
-    def read_traffic(pattern):
-        """-> (bytes per launch, bytes / the collection's own algorithmic bytes, source file, note)"""
+    def read_traffic(stem):
+        """-> (bytes per launch, bytes / the collection's own algorithmic bytes, source file, note).  ``stem``: file name after the round tag;
+        a round may hold several collections of one mode (``<tag>_<stem>.json``, ``<tag>_<stem>_steps20.json`` ...: one per launch population)
+        -- the newest round's file whose population is this run's is quoted, else the reason the newest one is not."""
+        import glob
+        first_note = None
         for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
-            tp = os.path.join(ROOT, "profiles", pattern.format(tag=tag))
-            if not os.path.isfile(tp):
-                continue
-            rel = os.path.relpath(tp, ROOT)
-            try:
-                with open(tp) as f:
-                    tj = json.load(f)
-            except Exception as e:
-                return None, None, rel, f"unreadable: {e!r}"
-            pop, ab = tj.get("population"), tj.get("algorithmic_bytes_per_launch")
-            if not pop or not ab:
-                return None, None, rel, "the newest PMC collection predates round 6 and does not record its launch population: not comparable"
-            diff = sorted(k_ for k_ in population if pop.get(k_) != population[k_])
-            if diff:
-                return None, None, rel, ("launch population differs from the PMC collection's in " +
-                                         ", ".join(f"{k_} ({population[k_]!r} here, {pop.get(k_)!r} there)" for k_ in diff))
-            if not alg_bytes_run or abs(ab / alg_bytes_run - 1.0) > 0.05:
-                return None, None, rel, f"algorithmic bytes per launch differ: {alg_bytes_run:.4g} here, {ab:.4g} in the PMC collection"
-            return tj["bytes_per_launch_corrected"], tj["bytes_per_launch_corrected"] / ab, rel, "same launch population as this run"
+            for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_{stem}*.json"))):
+                rel = os.path.relpath(tp, ROOT)
+                try:
+                    with open(tp) as f:
+                        tj = json.load(f)
+                except Exception as e:
+                    first_note = first_note or (rel, f"unreadable: {e!r}")
+                    continue
+                pop, ab = tj.get("population"), tj.get("algorithmic_bytes_per_launch")
+                if not pop or not ab:
+                    first_note = first_note or (rel, "the newest PMC collection predates round 6 and does not record its launch population: not comparable")
+                    continue
+                diff = sorted(k_ for k_ in population if pop.get(k_) != population[k_])
+                if diff:
+                    first_note = first_note or (rel, "launch population differs from the PMC collection's in " +
+                                                ", ".join(f"{k_} ({population[k_]!r} here, {pop.get(k_)!r} there)" for k_ in diff))
+                    continue
+                if not alg_bytes_run or abs(ab / alg_bytes_run - 1.0) > 0.05:
+                    first_note = first_note or (rel, f"algorithmic bytes per launch differ: {alg_bytes_run:.4g} here, {ab:.4g} in the PMC collection")
+                    continue
+                return tj["bytes_per_launch_corrected"], tj["bytes_per_launch_corrected"] / ab, rel, "same launch population as this run"
+            if first_note:
+                break                     # an older round's kernels are not this round's
+        if first_note:
+            return None, None, first_note[0], first_note[1]
         return None, None, None, "no PMC collection under profiles/"
 
     # the newest collection of THIS mode (tools/collect_profiles.sh); files without a mode suffix are the native-f32 kernels'
     sfx = {"f32": "", "f32x3": "_f32x3", "bf16": "_bf16", "bf16_exact": "_bf16_exact"}[args.weights]
-    traffic, traffic_ratio, traffic_src, traffic_note = read_traffic("{tag}_pmc_gemm_traffic" + sfx + ".json")
+    traffic, traffic_ratio, traffic_src, traffic_note = read_traffic("pmc_gemm_traffic" + sfx)
 
     # f32 weights: native f32 MFMA, algorithmic = executed flops.  bf16 weights: each algorithmic product is
     # three bf16 MFMA products (exact activation split), priced against the dense bf16 peak.
     bound = "mfma"
     if args.heuristic == "yolo":
         gemm_kernel, peak, exec_mult, bound = "conv_valu_kernel + conv_sw_kernel (implicit-GEMM convolutions, v_pk_fma_f32, no MFMA)", FP32_MFMA_PEAK_TFLOPS, 1.0, "valu"
-        traffic, traffic_ratio, traffic_src, traffic_note = read_traffic("{tag}_yolo_pmc_conv_traffic.json")      # tools/collect_yolo_profiles.sh
+        traffic, traffic_ratio, traffic_src, traffic_note = read_traffic("yolo_pmc_conv_traffic")      # tools/collect_yolo_profiles.sh
     elif args.weights == "bf16":
         gemm_kernel, peak, exec_mult = "gemm_bf16w2_wide_kernel / gemm_f32_kernel<WMODE=3> (2 x v_mfma_f32_32x32x16_bf16 per K=16)", BF16_MFMA_PEAK_TFLOPS, 2.0
     elif args.weights == "bf16_exact":

@@ -15,14 +15,14 @@ PY="python $ROOT/bench.py"
 # 1. the secondary workloads (the bench line itself runs last, after the counter passes, so that its
 #    roofline.traffic field is this collection's figure)
 : > "$OUT/bench.err"
-$PY --steps 32 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights f32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_f32_native.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --weights bf16_exact --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_config5_exact_split.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
-$PY --steps 8 --warmup 1 --workload haystack --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_haystack_1gpu.json" 2>> "$OUT/bench.err"
-$PY --workload haystack32 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_haystack32_1gpu.json" 2>> "$OUT/bench.err"
+$PY --steps 32 --warmup 1 --grid 4 --lockstep 16 --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_grid4_lockstep16.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16 --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_bf16_weights.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights f32 --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_f32_native.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16 --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_config5.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --weights bf16_exact --nframes 14400 --grid 15 --search-nframes 32 --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_config5_exact_split.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --concurrency 2 --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_concurrency2.json" 2>> "$OUT/bench.err"
+$PY --steps 8 --warmup 1 --workload haystack --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_haystack_1gpu.json" 2>> "$OUT/bench.err"
+$PY --workload haystack32 --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_haystack32_1gpu.json" 2>> "$OUT/bench.err"
 
 # 1b. YOLO-World backend: its own script (bench line, kernel trace, per-shape and per-layer tables, counters)
 bash $ROOT/tools/collect_yolo_profiles.sh $TAG
@@ -32,7 +32,7 @@ cd /tmp
 #    verification, config.grid4 -- run too; the timed region is cut out of the trace at the marker kernels bench.py
 #    enqueues around it, tools/rocpd_window.py)
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $PY --steps 16 --warmup 1 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/rocprof_kt.err"
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $PY --steps 16 --warmup 1 --no-cpu-baseline --no-other-configs --no-drop-in > "$OUT/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/rocprof_kt.err"
 DB=$(find /tmp/prof_kt -name '*.db' | head -1)
 BJ="$OUT/${TAG}_bench_under_rocprofv3.json"
 python $ROOT/tools/rocpd_stats.py "$DB" > "$OUT/${TAG}_rocprofv3_kernel_stats.md"
@@ -59,12 +59,29 @@ M=$(find /tmp/prof_SQ_VALU_MFMA_BUSY_CYCLES_GRBM_GUI_ACTIVE -name '*.db' | head 
 M2=$(find /tmp/prof_SQ_INSTS_VALU_MFMA_MOPS_F32_SQ_BUSY_CYCLES -name '*.db' | head -1)
 python $ROOT/tools/rocpd_traffic.py "$F" "$W" "gemm_f32|gemm_bf16w2_wide" "" "$OUT/pmc_pass_FETCH_SIZE.json" > "$OUT/${TAG}_pmc_gemm_traffic_f32x3.json"      # the bench default is the f32x3 mode since round 5
 python $ROOT/tools/rocpd_pmc.py "$F" "$W" > "$OUT/${TAG}_pmc_fetch_write_by_kernel.md"
+# the same two counters on the DRIVER's launch population (--steps 20: two lock-step groups of 10), so that the driver's line can quote a like-for-like figure too
+for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/prof20_$C
+    timeout 400 rocprofv3 --kernel-trace --pmc $C -d /tmp/prof20_$C -o pmc -- $PY --steps 20 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify --no-other-configs --no-drop-in > "$OUT/pmc_pass20_$C.json" 2> "$OUT/rocprof20_$C.err"
+done
+python $ROOT/tools/rocpd_traffic.py "$(find /tmp/prof20_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/prof20_WRITE_SIZE -name '*.db' | head -1)" "gemm_f32|gemm_bf16w2_wide" \
+    "rocprofv3 --kernel-trace --pmc <COUNTER> -- python bench.py --steps 20 --warmup 0 --no-cpu-baseline --no-grid4 --no-verify --no-other-configs --no-drop-in (tools/collect_profiles.sh)" \
+    "$OUT/pmc_pass20_FETCH_SIZE.json" > "$OUT/${TAG}_pmc_gemm_traffic_f32x3_steps20.json"
+cp "$OUT/${TAG}_pmc_gemm_traffic_f32x3_steps20.json" "$ROOT/profiles/${TAG}_pmc_gemm_traffic_f32x3_steps20.json"
 python $ROOT/tools/rocpd_pmc.py "$M" "$M2" > "$OUT/${TAG}_pmc_mfma_by_kernel.md"
 python $ROOT/tools/rocpd_mfma.py "$M" > "$OUT/${TAG}_pmc_mfma_utilisation.md"
 
 # 4. the bench line (default flags), reading the traffic figure just collected
 cp "$OUT/${TAG}_pmc_gemm_traffic_f32x3.json" "$ROOT/profiles/${TAG}_pmc_gemm_traffic_f32x3.json"
 $PY > "$OUT/${TAG}_bench.json" 2>> "$OUT/bench.err"
+$PY --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_shape.json" 2>> "$OUT/bench.err"
+
+# 4b. one reference-default 4x4 search alone (the drop-in user's latency): A/Bs, kernel table, idle gaps, per-stream view
+bash $ROOT/tools/solo_grid4_trace.sh > "$OUT/solo_trace.log" 2>&1
+for f in solo_grid4_probe.log solo_grid4_kernel_stats.md solo_grid4_gaps.txt solo_grid4_streams.txt; do
+    [ -f "$ROOT/gpurun_out/$f" ] && cp "$ROOT/gpurun_out/$f" "$OUT/${TAG}_$f"
+done
+cd /tmp
 
 # 5. kernel microbenchmarks
 rm -rf /tmp/prof_sf
