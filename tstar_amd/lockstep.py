@@ -86,6 +86,7 @@ class _Group:
         self.pending = None            # the verification batch in flight (end() consumes it)
         self.act = []
         self.spec = None               # the NEXT iteration's samples / grid forward, queued speculatively (see speculate())
+        self.spec_beside = False       # ... which runs beside the verification batch (auxiliary stream, lane 1), not behind it
         self.ahead = None              # ... and its verification batch, queued behind the one in flight (see verify_ahead())
         self.vq = self.masks = None    # the verification batch of THIS iteration (verify_launch()) and the grid's cell masks
         self.solo = False              # one searcher driven through its own slot 0 and its public sample_frames hook
@@ -216,6 +217,7 @@ class _Group:
             ev = torch.cuda.Event()
             ev.record(stream)
         self.spec = (items, secs_l, grids, res, ev, states, warned)
+        self.spec_beside = beside
 
     def _drop_speculation(self):
         if self.ahead is not None:
@@ -443,8 +445,9 @@ def search_solo(searcher: TStarSearcher) -> Tuple[np.ndarray, list]:
         g.update()                     # write-back, fit, P, histories of iteration t (its verification batch is running)
         if _SPECULATE:
             g.speculate()              # samples and grid forward of iteration t + 1, beside the verification batch
-            if _AHEAD and not g.verification_done():
-                g.verify_ahead()       # ... and its verification batch behind the one in flight
+            if _AHEAD and g.spec_beside and not g.verification_done():
+                g.verify_ahead()       # ... and its verification batch behind the one in flight (a forward queued BEHIND the running
+                                       # batch -- a detector without a second workspace -- would only make the host wait for both)
         g.end()                        # verification results of iteration t, replay
         if not g.act:
             break
