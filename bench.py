@@ -270,6 +270,45 @@ def drop_in_record(store, k):
     return out
 
 
+def match_traffic(population, alg_bytes_run, stem, profiles_dir=None):
+    """The PMC traffic figure of the dominant kernel for THIS run, or the reason there is none:
+    -> (bytes per launch, bytes / the collection's own algorithmic bytes, source file, note).  ``stem``: file name after the round tag; a
+    round may hold several collections of one mode (``<tag>_<stem>.json``, ``<tag>_<stem>_steps20.json`` ...: one per launch population).
+    The newest round's file whose population is this run's (same flags that shape the launches, and its own algorithmic bytes per launch
+    within 5 % of this run's) is quoted; otherwise the first reason met in the newest round -- a per-launch byte count of one population
+    divided by another's algorithmic bytes is not a ratio of anything (round 5 printed 0.28x ... 1.83x that way)."""
+    import glob
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    first_note = None
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
+        for tp in sorted(glob.glob(os.path.join(profiles_dir, f"{tag}_{stem}*.json"))):
+            rel = os.path.relpath(tp, os.path.dirname(profiles_dir))
+            try:
+                with open(tp) as f:
+                    tj = json.load(f)
+            except Exception as e:
+                first_note = first_note or (rel, f"unreadable: {e!r}")
+                continue
+            pop, ab = tj.get("population"), tj.get("algorithmic_bytes_per_launch")
+            if not pop or not ab:
+                first_note = first_note or (rel, "the newest PMC collection predates round 6 and does not record its launch population: not comparable")
+                continue
+            diff = sorted(k_ for k_ in population if pop.get(k_) != population[k_])
+            if diff:
+                first_note = first_note or (rel, "launch population differs from the PMC collection's in " +
+                                            ", ".join(f"{k_} ({population[k_]!r} here, {pop.get(k_)!r} there)" for k_ in diff))
+                continue
+            if not alg_bytes_run or abs(ab / alg_bytes_run - 1.0) > 0.05:
+                first_note = first_note or (rel, f"algorithmic bytes per launch differ: {alg_bytes_run:.4g} here, {ab:.4g} in the PMC collection")
+                continue
+            return tj["bytes_per_launch_corrected"], tj["bytes_per_launch_corrected"] / ab, rel, "same launch population as this run"
+        if first_note:
+            break                         # an older round's kernels are not this round's
+    if first_note:
+        return None, None, first_note[0], first_note[1]
+    return None, None, None, "no PMC collection under profiles/"
+
+
 def lockstep_group_sizes(n, L, PL):
     """Sizes of the lock-step groups `n` items are run in: groups of at most about L items, balanced (5 items at L = 4 -> 3 + 2, not
     4 + 1), their count a multiple of the alternation depth PL when n allows it -- a count that is not leaves the last group without a
@@ -862,39 +901,7 @@ def main():
                   "search_nframes": args.search_nframes, "workload_kind": workload, "n_gpus": world, "concurrency": conc}
     alg_bytes_run = by.value / max(n_l.value, 1)
 
-    def read_traffic(stem):
-        """-> (bytes per launch, bytes / the collection's own algorithmic bytes, source file, note).  ``stem``: file name after the round tag;
-        a round may hold several collections of one mode (``<tag>_<stem>.json``, ``<tag>_<stem>_steps20.json`` ...: one per launch population)
-        -- the newest round's file whose population is this run's is quoted, else the reason the newest one is not."""
-        import glob
-        first_note = None
-        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
-            for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_{stem}*.json"))):
-                rel = os.path.relpath(tp, ROOT)
-                try:
-                    with open(tp) as f:
-                        tj = json.load(f)
-                except Exception as e:
-                    first_note = first_note or (rel, f"unreadable: {e!r}")
-                    continue
-                pop, ab = tj.get("population"), tj.get("algorithmic_bytes_per_launch")
-                if not pop or not ab:
-                    first_note = first_note or (rel, "the newest PMC collection predates round 6 and does not record its launch population: not comparable")
-                    continue
-                diff = sorted(k_ for k_ in population if pop.get(k_) != population[k_])
-                if diff:
-                    first_note = first_note or (rel, "launch population differs from the PMC collection's in " +
-                                                ", ".join(f"{k_} ({population[k_]!r} here, {pop.get(k_)!r} there)" for k_ in diff))
-                    continue
-                if not alg_bytes_run or abs(ab / alg_bytes_run - 1.0) > 0.05:
-                    first_note = first_note or (rel, f"algorithmic bytes per launch differ: {alg_bytes_run:.4g} here, {ab:.4g} in the PMC collection")
-                    continue
-                return tj["bytes_per_launch_corrected"], tj["bytes_per_launch_corrected"] / ab, rel, "same launch population as this run"
-            if first_note:
-                break                     # an older round's kernels are not this round's
-        if first_note:
-            return None, None, first_note[0], first_note[1]
-        return None, None, None, "no PMC collection under profiles/"
+    read_traffic = lambda stem: match_traffic(population, alg_bytes_run, stem)
 
     # the newest collection of THIS mode (tools/collect_profiles.sh); files without a mode suffix are the native-f32 kernels'
     sfx = {"f32": "", "f32x3": "_f32x3", "bf16": "_bf16", "bf16_exact": "_bf16_exact"}[args.weights]

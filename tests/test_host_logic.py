@@ -686,6 +686,34 @@ def test_bench_lockstep_group_sizes():
                     assert len(sz) % PL == 0 or len(sz) == n, (n, L, PL, sz)
 
 
+def test_bench_traffic_is_only_quoted_for_the_same_launch_population(tmp_path):
+    """bench.match_traffic (round 6, review item 2): `roofline.traffic` comes from committed PMC collections; a collection is quoted only for
+    a run of the SAME launch population (the flags that shape the launches + its own algorithmic bytes per launch within 5 %), several
+    collections of one round are told apart by population, a collection without a recorded population is refused, and an older round's file
+    is never used once the newest round has one."""
+    import json as J
+    import bench
+    d = tmp_path / "profiles"
+    d.mkdir()
+    pop16 = {"heuristic": "owl", "weights": "f32x3", "steps": 16, "lockstep": 8, "pipeline": 2, "max_batch": 512, "grid": 16, "nframes": 3600,
+             "search_nframes": 8, "workload_kind": "single", "n_gpus": 1, "concurrency": 1}
+    pop20 = dict(pop16, steps=20)
+    (d / "r05_pmc_gemm_traffic_f32x3.json").write_text(J.dumps({"bytes_per_launch_corrected": 2.7e9}))                  # round 5: no population
+    assert bench.match_traffic(pop16, 1.33e9, "pmc_gemm_traffic_f32x3", str(d))[0] is None
+    assert "predates round 6" in bench.match_traffic(pop16, 1.33e9, "pmc_gemm_traffic_f32x3", str(d))[3]
+    (d / "r06_pmc_gemm_traffic_f32x3.json").write_text(J.dumps({"bytes_per_launch_corrected": 2.8e9, "population": pop16, "algorithmic_bytes_per_launch": 1.35e9}))
+    (d / "r06_pmc_gemm_traffic_f32x3_steps20.json").write_text(J.dumps({"bytes_per_launch_corrected": 3.1e9, "population": pop20, "algorithmic_bytes_per_launch": 1.50e9}))
+    t, ratio, src, note = bench.match_traffic(pop16, 1.33e9, "pmc_gemm_traffic_f32x3", str(d))
+    assert t == 2.8e9 and abs(ratio - 2.8 / 1.35) < 1e-12 and src.endswith("r06_pmc_gemm_traffic_f32x3.json") and "same launch population" in note
+    t, ratio, src, note = bench.match_traffic(pop20, 1.49e9, "pmc_gemm_traffic_f32x3", str(d))
+    assert t == 3.1e9 and src.endswith("_steps20.json")
+    t, ratio, src, note = bench.match_traffic(dict(pop16, steps=3), 1.2e9, "pmc_gemm_traffic_f32x3", str(d))
+    assert t is None and ratio is None and "steps (3 here, 16 there)" in note and "r06_" in src          # never the r05 file
+    t, _, _, note = bench.match_traffic(pop16, 2.0e9, "pmc_gemm_traffic_f32x3", str(d))
+    assert t is None and "algorithmic bytes per launch differ" in note
+    assert bench.match_traffic(pop16, 1.3e9, "yolo_pmc_conv_traffic", str(d)) == (None, None, None, "no PMC collection under profiles/")
+
+
 def test_bench_self_spawn_command(monkeypatch):
     """`python bench.py --gpus N` typed without a launcher (WORLD_SIZE unset) starts its own ranks: the command is the driver's
     (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1, the user's flags passed through), launcher variables of
