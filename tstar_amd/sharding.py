@@ -81,6 +81,13 @@ def _tstar_comm(world: int, rank: int):
     import torch.distributed as dist
     from . import _lib
     lib = _lib.load()
+    # ONE RCCL in the process: torch.distributed's "nccl" backend has already loaded the copy PyTorch ships; hand the library that very
+    # file (dlopen of a loaded file returns the loaded object) instead of letting the bare name "librccl.so" resolve through the linker
+    # cache to another installation's copy.  TSTAR_RCCL_LIB set by the user wins.
+    if not os.environ.get("TSTAR_RCCL_LIB"):
+        cand = os.path.join(os.path.dirname(os.path.abspath(torch.__file__)), "lib", "librccl.so")
+        if os.path.isfile(cand):
+            os.environ["TSTAR_RCCL_LIB"] = cand
     # every rank binds RCCL locally FIRST and the outcome is MIN-reduced: ncclCommInitRank is collective, so a rank that
     # cannot load the library must be known before any rank enters it (the others would block inside it forever)
     have = 1 if lib.tstar_comm_available() == 0 else 0
