@@ -312,7 +312,9 @@ int tstar_gemm_f32_cfg(const float* d_A, const float* d_W, float* d_C, const flo
 /* bf16-weight GEMM (diagnostic): W is rounded to bfloat16 on the device, A is split exactly; synchronises */
 int tstar_gemm_bf16w(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                      int M, int N, int K, int act, int tile_cfg, void* stream);
-/* bf16-weight GEMM with two-term activations (diagnostic; tile_cfg 4 forces the 128x256 tile, 5 forbids it) */
+/* bf16-weight GEMM with two-term activations (diagnostic; tile_cfg 4 forces the 128x256 tile, 5 forbids it, 6 (round 6; needs N % 256 == 0 and
+ * M >= 128) forces the 128x256 tile whose weight fragments stream global -> VGPR from a fragment-packed plane -- what the library picks by itself
+ * for the N = 768 layers; every choice returns the same bits) */
 int tstar_gemm_bf16w2(const float* d_A, const float* d_W, float* d_C, const float* d_bias, const float* d_residual,
                       int M, int N, int K, int act, int tile_cfg, void* stream);
 /* bf16-weight GEMM on weights that are ALREADY bfloat16 on the device (d_Wb: [N, K] bf16); a_terms 2 or 3; enqueues only
