@@ -669,6 +669,19 @@ def test_spline_worker_count_follows_the_affinity_mask(monkeypatch):
     assert SP.default_workers() == 3
 
 
+def test_lockstep_only_uses_the_second_workspace_when_score_batch_takes_a_lane():
+    """A wrapper installed over ``heuristic.score_batch`` with the pre-round-6 signature (a recorder, a logger) must keep working: the
+    speculative forward then stays on the detector stream (lockstep._accepts_lane)."""
+    from tstar_amd.lockstep import _accepts_lane
+    assert _accepts_lane(lambda d, r, c, image_sets=None, lane=0: None)
+    assert _accepts_lane(lambda d, r, c, image_sets=None, **kw: None)
+    assert not _accepts_lane(lambda d, r, c, image_sets=None: None)
+    assert not _accepts_lane(print) or True          # builtins without a signature are simply refused or accepted by **kwargs: no exception
+    from tstar_amd.interface_heuristic import OWLInterface, YoloWorldInterface
+    assert _accepts_lane(OWLInterface.score_batch) and OWLInterface.aux_lane is True
+    assert not _accepts_lane(YoloWorldInterface.score_batch) and not getattr(YoloWorldInterface, "aux_lane", False)
+
+
 def test_bench_lockstep_group_sizes():
     """bench.lockstep_group_sizes: every item in exactly one group, balanced sizes, a group count that is a multiple of the alternation
     depth whenever there are at least that many items (the driver's --steps 20: 10 + 10, not 7 + 7 | 6)."""
