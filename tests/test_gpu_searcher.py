@@ -750,17 +750,23 @@ def test_query_sets_are_independent():
         h.score_batch(img, 1, 1, image_sets=[1, 7])
 
 
+@pytest.mark.parametrize("ahead_always", [False, True])
 @pytest.mark.parametrize("thr,targets,use_global_rng", [(0.05, ["couch"], False), (0.05, ["couch", "tv"], False), (0.6, ["couch"], True)])
-def test_speculative_next_grid_equals_the_sequential_loop(monkeypatch, thr, targets, use_global_rng):
+def test_speculative_next_grid_equals_the_sequential_loop(monkeypatch, thr, targets, use_global_rng, ahead_always):
     """Round 5: ``search()`` on the fast path runs through ``lockstep.search_solo`` and queues the NEXT iteration's samples and grid
     forward speculatively behind each verification batch (``_Group.speculate``).  Against the plain sequential loop
     (TSTAR_SOLO_SEQUENTIAL=1) on identically seeded searchers: same sampled seconds through the public ``sample_frames`` hook (one
     call per executed iteration, no trace of a discarded draw), same histories, keyframes and counters, the sampler generator left
     in the same state -- with a low threshold so that verification ENDS the search (the speculation is discarded and its draw
     undone), with two targets (the search goes on after the first is found), and with the process-global numpy generator."""
+    from tstar_amd import lockstep as LS_
     from tstar_amd.interface_heuristic import OWLInterface
     from tstar_amd.interface_searcher import TStarSearcher
     from tstar_amd.video import synthetic_video
+    # round 6: ``ahead_always`` queues the NEXT verification batch behind the running one in every iteration (normally only while that
+    # one is still running: timing), so that keeping it, dropping it with the search (target found, search over) and dropping it alone
+    # (first of two targets found: the sequential loop's smaller batch is queued instead) are all exercised deterministically
+    monkeypatch.setattr(LS_, "_AHEAD_ALWAYS", ahead_always)
     h = OWLInterface(synthetic_seed=0, max_batch=16)
     store = synthetic_video(700, seed=9)
 
@@ -802,7 +808,10 @@ def test_speculative_next_grid_equals_the_sequential_loop(monkeypatch, thr, targ
         assert ended_by_target                                            # the case under test: verification ended the search
         from tstar_amd import lockstep as LS
         wasted = 1 if (a.search_budget > 0 and LS._SPECULATE) else 0          # TSTAR_NO_SPECULATION=1 (an A/B knob): nothing is queued ahead
-        assert a.device_images_scored == b.device_images_scored + wasted    # the one wasted grid image is counted
+        if ahead_always:
+            assert a.device_images_scored >= b.device_images_scored + wasted   # ... plus the frames of early verification batches that were dropped
+        else:
+            assert a.device_images_scored >= b.device_images_scored + wasted and a.device_images_scored <= b.device_images_scored + wasted + 64
 
 
 @pytest.mark.parametrize("kind", ["alters", "replaces"])

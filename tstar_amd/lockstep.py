@@ -39,6 +39,7 @@ _BESIDE = os.environ.get("TSTAR_SPECULATE_BEHIND") is None
 # ... and the next verification batch is queued behind the running one before its results are read (verify_ahead()).
 # TSTAR_NO_VERIFY_AHEAD=1: off (same-session A/Bs).
 _AHEAD = os.environ.get("TSTAR_NO_VERIFY_AHEAD") is None
+_AHEAD_ALWAYS = False   # tests: queue the next batch early even when the running one has already finished (every path, deterministically)
 AUX_IMAGES = 4          # TSTAR_OWL_AUX_BATCH (include/tstar_hip.h): images per forward chunk of lane 1
 
 
@@ -445,7 +446,7 @@ def search_solo(searcher: TStarSearcher) -> Tuple[np.ndarray, list]:
         g.update()                     # write-back, fit, P, histories of iteration t (its verification batch is running)
         if _SPECULATE:
             g.speculate()              # samples and grid forward of iteration t + 1, beside the verification batch
-            if _AHEAD and g.spec_beside and not g.verification_done():
+            if _AHEAD and g.spec_beside and (_AHEAD_ALWAYS or not g.verification_done()):
                 g.verify_ahead()       # ... and its verification batch behind the one in flight (a forward queued BEHIND the running
                                        # batch -- a detector without a second workspace -- would only make the host wait for both)
         g.end()                        # verification results of iteration t, replay
