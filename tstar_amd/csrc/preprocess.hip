@@ -684,6 +684,95 @@ __global__ __launch_bounds__(256) void bilinear_gather_nv12_kernel(const uint8_t
     else { d[0] = (uint8_t)v[0][0]; d[1] = (uint8_t)v[0][1]; d[2] = (uint8_t)v[0][2]; }
 }
 
+// Round 6: the NV12 resize with every SOURCE pixel converted once.  The kernel above converts per tap -- four BT.601 conversions (~13
+// VALU each) per output pixel -- although a 360x640 -> 285x600 resize reads only 1.35 source pixels per output pixel.  Here a block
+// owns an 8 x 128 tile of the output: it converts the source region the tile's taps fall in (rows ty[first].s0 .. ty[last].s1, columns
+// from tx[first].s0 rounded down to a multiple of 4) to packed RGB in LDS -- 4 luma bytes + the 2 UV pairs they share per lane and
+// step, one ds_write_b128 -- and then mixes 4 output pixels per lane from LDS with the same fixed-point formulas (v_perm_b32 +
+// v_dot2_u32_u16 horizontally, vmix vertically): same bits, ~65 instead of ~110 VALU per output pixel.  Needs W % 4 == 0 and
+// ow % 4 == 0 (the launcher falls back to the per-tap kernel otherwise); the region's size is computed on the host per
+// (H, W, oh, ow) and bounds the dynamic LDS.
+constexpr int NV_TR = 8, NV_TC = 128;
+__global__ __launch_bounds__(256) void bilinear_gather_nv12_lds_kernel(const uint8_t* __restrict__ video, size_t frame_bytes, const int* __restrict__ idx,
+                                                                       int H, int W, int ow, int oh, int tiles_x, int pitch,
+                                                                       const int4* __restrict__ tx, const int4* __restrict__ ty, uint8_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned nv_region[];
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int oy0 = tyi * NV_TR, ox0 = txi * NV_TC;
+    const int oy1 = (oy0 + NV_TR < oh ? oy0 + NV_TR : oh) - 1, ox1 = (ox0 + NV_TC < ow ? ox0 + NV_TC : ow) - 1;
+    const uint8_t* f = video + (size_t)idx[blockIdx.y] * frame_bytes;     // block-uniform
+    const int ry0 = ty[oy0].x, ry1 = ty[oy1].y;
+    const int rx0 = tx[ox0].x & ~3, rx1 = tx[ox1].y;
+    const int nrows = ry1 - ry0 + 1, ncols4 = ((rx1 - rx0) >> 2) + 1;
+    // ---- phase 1: source region -> packed RGB (r | g << 8 | b << 16) in LDS
+    const int items = nrows * ncols4;
+    const float inv = 1.0f / (float)ncols4;
+    const size_t hw = (size_t)H * W;
+    for (int it = t; it < items; it += 256) {
+        const int r = (int)(((float)it + 0.5f) * inv);                    // it / ncols4 (exact: it < 2^13, the half keeps clear of the rounding)
+        const int c4 = it - r * ncols4;
+        const int sy = ry0 + r, sx = rx0 + 4 * c4;
+        const unsigned lu = *reinterpret_cast<const unsigned*>(f + (size_t)sy * W + sx);
+        const unsigned ch = *reinterpret_cast<const unsigned*>(f + hw + (size_t)(sy >> 1) * W + sx);
+        uint4 o;
+        unsigned rgb[3];
+        nv12_tap(lu, ch, 0u | 0x0C00u | (4u << 16) | 0x0C000000u, rgb); o.x = rgb[0] | (rgb[1] << 8) | (rgb[2] << 16);
+        nv12_tap(lu, ch, 1u | 0x0C00u | (4u << 16) | 0x0C000000u, rgb); o.y = rgb[0] | (rgb[1] << 8) | (rgb[2] << 16);
+        nv12_tap(lu, ch, 2u | 0x0C00u | (6u << 16) | 0x0C000000u, rgb); o.z = rgb[0] | (rgb[1] << 8) | (rgb[2] << 16);
+        nv12_tap(lu, ch, 3u | 0x0C00u | (6u << 16) | 0x0C000000u, rgb); o.w = rgb[0] | (rgb[1] << 8) | (rgb[2] << 16);
+        *reinterpret_cast<uint4*>(nv_region + r * pitch + 4 * c4) = o;
+    }
+    __syncthreads();
+    // ---- phase 2: 4 consecutive output pixels of one row per lane
+    const int oy = oy0 + (t >> 5), ox = ox0 + 4 * (t & 31);
+    if (oy > oy1 || ox > ox1) return;
+    const int4 ye = ty[oy];
+    const unsigned* row0 = nv_region + (ye.x - ry0) * pitch - rx0;
+    const unsigned* row1 = nv_region + (ye.y - ry0) * pitch - rx0;
+    const unsigned b0 = (unsigned)ye.z << 12, b1 = (unsigned)ye.w << 12;
+    unsigned v[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int4 xe = tx[ox + k];
+        const unsigned w = (unsigned)xe.z | ((unsigned)xe.w << 16);
+        const unsigned p00 = row0[xe.x], p01 = row0[xe.y], p10 = row1[xe.x], p11 = row1[xe.y];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned sel = (unsigned)c | 0x0C00u | ((4u + c) << 16) | 0x0C000000u;      // byte c of the left tap | byte c of the right tap << 16
+            v[k][c] = vmix(hmix(p01, p00, sel, w), hmix(p11, p10, sel, w), b0, b1);
+        }
+    }
+    store_px4(out + (((size_t)blockIdx.y * oh + oy) * ow + ox) * 3, v);
+}
+
+// largest source region (rows, 4-pixel column groups) any 8 x 128 output tile of a (H, W) -> (oh, ow) resize needs
+static void nv12_lds_region(int H, int W, int oh, int ow, int* max_rows, int* max_cols4) {
+    auto entry = [](int src, int dst, int d, int* s0, int* s1) {
+        const double scale = (double)src / dst;
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        if (s < 0) s = 0;
+        if (s >= src - 1) s = src - 1;
+        *s0 = s; *s1 = s + 1 < src ? s + 1 : src - 1;
+    };
+    int mr = 0, mc = 0;
+    for (int y0 = 0; y0 < oh; y0 += NV_TR) {
+        int a, b, c, d;
+        entry(H, oh, y0, &a, &b);
+        entry(H, oh, (y0 + NV_TR < oh ? y0 + NV_TR : oh) - 1, &c, &d);
+        if (d - a + 1 > mr) mr = d - a + 1;
+    }
+    for (int x0 = 0; x0 < ow; x0 += NV_TC) {
+        int a, b, c, d;
+        entry(W, ow, x0, &a, &b);
+        entry(W, ow, (x0 + NV_TC < ow ? x0 + NV_TC : ow) - 1, &c, &d);
+        const int n = ((d - (a & ~3)) >> 2) + 1;
+        if (n > mc) mc = n;
+    }
+    *max_rows = mr; *max_cols4 = mc;
+}
+
 // TSTAR_INGEST_GENERIC=1 forces the generic kernels on RGB sources too (before / after counter runs, tools/pmc_ingest_counters.sh)
 static bool rgb_fast_ok(int W, long long npix, int div) {
     static const bool generic = [] { const char* e = getenv("TSTAR_INGEST_GENERIC"); return e && atoi(e) != 0; }();
@@ -744,6 +833,22 @@ int bilinear_gather_u8(const uint8_t* video, int H, int W, const int* d_idx, int
         else hipLaunchKernelGGL(bilinear_gather_rgb_kernel<1>, g, dim3(256), 0, s, video, (size_t)H * W * 3, d_idx, ow, owq, magic_of(owq), nunits, fx, fy, out);
         TSTAR_HIP_CHECK(hipGetLastError());
         return TSTAR_OK;
+    }
+    // TSTAR_NV12_LDS=0: the per-tap kernel everywhere (same-session A/Bs)
+    static const bool nv12_lds = [] { const char* e = getenv("TSTAR_NV12_LDS"); return !(e && atoi(e) == 0); }();
+    if (nv12 && nv12_lds && n <= 65535 && W % 4 == 0 && H % 2 == 0 && ow % 4 == 0 && ow >= 4 && (reinterpret_cast<size_t>(out) & 3) == 0 &&
+        (reinterpret_cast<size_t>(video) & 3) == 0 && (size_t)H * W * 3 / 2 < (1ull << 31) && ((size_t)H * W * 3 / 2) % 4 == 0) {
+        int mr, mc;
+        nv12_lds_region(H, W, oh, ow, &mr, &mc);
+        const int pitch = mc * 4 + 4;                                     // dwords; rows stay 16-byte aligned, consecutive rows shifted by 4 banks
+        const size_t lds = (size_t)mr * pitch * 4;
+        if (lds <= 64 * 1024 && mr * mc < 8192) {
+            const int tiles_x = (ow + NV_TC - 1) / NV_TC, tiles_y = (oh + NV_TR - 1) / NV_TR;
+            hipLaunchKernelGGL(bilinear_gather_nv12_lds_kernel, dim3((unsigned)(tiles_x * tiles_y), (unsigned)n), dim3(256), lds, s, video,
+                               (size_t)H * W * 3 / 2, d_idx, H, W, ow, oh, tiles_x, pitch, tx, ty, out);
+            TSTAR_HIP_CHECK(hipGetLastError());
+            return TSTAR_OK;
+        }
     }
     if (nv12 && n <= 65535 && W >= 4 && W <= 65535 && W % 2 == 0 && H % 2 == 0 && rgb_fast_ok(W, (long long)ow * oh, ow) && (size_t)H * W * 3 / 2 < (1ull << 31)) {
         const uint4 *fx, *fy;
