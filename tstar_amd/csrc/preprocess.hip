@@ -91,6 +91,15 @@ __device__ __forceinline__ uint8_t clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// 12 bytes of 4 consecutive RGB pixels -> three aligned dword stores
+__device__ __forceinline__ void store_px4_bytes(uint8_t* d, const unsigned (&v)[4][3]) {
+    uint3 o;
+    o.x = v[0][0] | (v[0][1] << 8) | (v[0][2] << 16) | (v[1][0] << 24);
+    o.y = v[1][1] | (v[1][2] << 8) | (v[2][0] << 16) | (v[2][1] << 24);
+    o.z = v[2][2] | (v[3][0] << 8) | (v[3][1] << 16) | (v[3][2] << 24);
+    *reinterpret_cast<uint3*>(d) = o;
+}
+
 // out[b,y,ox,:] = clip8(2^21 + sum_i in[b,y,xmin+i,:] * k[ox][i])
 __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                          int H, int W, int OW, int ksize,
@@ -105,10 +114,10 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restri
     const int* k = coefs + (size_t)ox * ksize;
     int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
     for (int i = 0; i < n; ++i) {
-        const int kk = k[i];
-        s0 += src[i * 3 + 0] * kk;
-        s1 += src[i * 3 + 1] * kk;
-        s2 += src[i * 3 + 2] * kk;
+        const int kk = k[i];                       // |k| <= 2^22 (1.0 in 22-bit fixed point) and a pixel <= 255: 24-bit operands, so the
+        s0 += __mul24(src[i * 3 + 0], kk);         // full-rate v_mad_i32_i24 computes the same 32-bit products as the quarter-rate
+        s1 += __mul24(src[i * 3 + 1], kk);         // v_mul_lo_u32 the compiler has to assume
+        s2 += __mul24(src[i * 3 + 2], kk);
     }
     uint8_t* dst = out + gid * 3;
     dst[0] = clip8(s0); dst[1] = clip8(s1); dst[2] = clip8(s2);
@@ -126,43 +135,65 @@ int resample_h_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, const Re
 // in u8 [B,H,768,3]; vertical pass to 768 rows; LUT normalise; write the patch-embed
 // A operand: row = b*576 + (y/32)*24 + x/32, col = c*1024 + (y%32)*32 + x%32.
 // One thread per (b, y, x); x fastest -> 32 consecutive threads write 128 contiguous bytes per channel.
+// Round 6: FOUR consecutive x per thread (12 source bytes = three dwords per tap and row instead of twelve byte loads, the products on the
+// full-rate v_mad_i32_i24 -- |k| <= 2^22, pixels <= 255: the same 32-bit values --, one float4 store per channel: 4 | 32, so the four stay in
+// one patch row), the normalisation LUT in LDS.  Same integers, same LUT entries: bit-exact (tests/test_gpu_detector.py::test_preprocess_*).
 __global__ __launch_bounds__(256) void resample_v_patchify_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
                                                                   uint8_t* __restrict__ out_u8, int H, int ksize,
                                                                   const int* __restrict__ bounds,
                                                                   const int* __restrict__ coefs,
-                                                                  const float* __restrict__ lut, size_t total) {
+                                                                  const float* __restrict__ lut, size_t total4) {
+    __shared__ float slut[768];
+    for (int i = threadIdx.x; i < 768; i += 256) slut[i] = lut[i];
+    __syncthreads();
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int x = (int)(gid % 768);
-    const int y = (int)((gid / 768) % 768);
-    const size_t b = gid / (768 * 768);
+    if (gid >= total4) return;
+    const int x = (int)(gid % 192) * 4;
+    const int y = (int)((gid / 192) % 768);
+    const size_t b = gid / (192 * 768);
     const int ymin = bounds[y * 2], n = bounds[y * 2 + 1];
-    const uint8_t* src = in + ((b * H + ymin) * 768 + x) * 3;
+    const uint8_t* src = in + ((b * H + ymin) * 768 + x) * 3;          // 12 bytes per tap row, dword-aligned (x % 4 == 0, rows of 2304 bytes)
     const int* k = coefs + (size_t)y * ksize;
-    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    int s[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[j][c] = 1 << 21;
     for (int i = 0; i < n; ++i) {
         const int kk = k[i];
-        const uint8_t* p = src + (size_t)i * 768 * 3;
-        s0 += p[0] * kk; s1 += p[1] * kk; s2 += p[2] * kk;
+        const unsigned* p = reinterpret_cast<const unsigned*>(src + (size_t)i * 768 * 3);
+        const unsigned w[3] = {p[0], p[1], p[2]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int byte = 3 * j + c;
+                s[j][c] += __mul24((int)((w[byte >> 2] >> ((byte & 3) * 8)) & 0xFFu), kk);
+            }
     }
-    const uint8_t v0 = clip8(s0), v1 = clip8(s1), v2 = clip8(s2);
-    if (out_u8) {
-        uint8_t* d = out_u8 + gid * 3;
-        d[0] = v0; d[1] = v1; d[2] = v2;
-    }
+    unsigned v[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[j][c] = clip8(s[j][c]);
+    if (out_u8) store_px4_bytes(out_u8 + ((b * 768 + y) * 768 + x) * 3, v);
     const size_t row = b * 576 + (size_t)(y >> 5) * 24 + (x >> 5);
     float* o = out + row * 3072 + (y & 31) * 32 + (x & 31);
-    o[0] = lut[v0];
-    o[1024] = lut[256 + v1];
-    o[2048] = lut[512 + v2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x4 q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = slut[c * 256 + v[j][c]];
+        *reinterpret_cast<f32x4*>(o + c * 1024) = q;
+    }
 }
 
 int resample_v_normalize_patchify(const uint8_t* in, float* out, uint8_t* out_u8, int B, int H, const ResampleTable& t,
                                   const float* lut, hipStream_t s) {
     TSTAR_REQUIRE(t.in_size == H && t.out_size == 768, "resample_v: table must map H -> 768");
-    const size_t total = (size_t)B * 768 * 768;
-    hipLaunchKernelGGL(resample_v_patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out,
-                       out_u8, H, t.ksize, t.d_bounds, t.d_coefs, lut, total);
+    const size_t total4 = (size_t)B * 768 * 192;                        // four consecutive x per thread
+    hipLaunchKernelGGL(resample_v_patchify_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, out,
+                       out_u8, H, t.ksize, t.d_bounds, t.d_coefs, lut, total4);
     TSTAR_HIP_CHECK(hipGetLastError());
     return TSTAR_OK;
 }
