@@ -137,8 +137,8 @@ int tstar_owl_score(tstar_owl* h, const uint8_t* d_images, int B, int H, int W, 
                     const int32_t* h_image_query_set, float* d_scores, int32_t* d_labels, float* d_boxes_xyxy, double* d_cell_conf,
                     uint32_t* d_cell_mask, int32_t* d_n_kept, float* d_logits, float* d_boxes_cxcywh, void* stream);
 /* Round 6 (an added entry point; tstar_abi_version() stays 3).  The same call on workspace `lane` (0 .. TSTAR_OWL_LANES - 1).  tstar_owl_score is lane 0, the handle's own workspace of
- * max_batch images.  Lane 1 is a second, SMALL workspace (forward chunks of min(max_batch, TSTAR_OWL_AUX_BATCH) images; allocated on
- * first use, which synchronises the device once): a call on lane 1 shares no mutable state with a call on lane 0, so the two may be
+ * max_batch images.  Lane 1 is a second, SMALL workspace (forward chunks of min(max_batch, max(TSTAR_OWL_AUX_BATCH, B)) images; allocated on
+ * first use and grown when a larger batch arrives, which synchronises the device once): a call on lane 1 shares no mutable state with a call on lane 0, so the two may be
  * enqueued on DIFFERENT streams and execute concurrently -- TStarSearcher queues the NEXT iteration's grid forward (one image: 120-456
  * wave tiles per GEMM for 1024 SIMDs) on lane 1 beside the verification batch of the iteration before (interface_searcher.py:444-491:
  * the loop the reference runs strictly one call after another).  Calls on ONE lane must stay ordered (one stream, or events), as

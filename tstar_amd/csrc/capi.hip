@@ -554,15 +554,21 @@ int tstar_owl_score_lane(tstar_owl* h, int lane, const uint8_t* d_images, int B,
     if (!h->has_vision) { set_error("tstar_owl_score: handle was created without vision weights (text-only)"); return TSTAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
     auto& L = h->lane[lane];
-    if (!L.x) {                                           // lane 1: allocated on first use (a one-off, like the resample tables)
-        const int cap = h->max_batch < TSTAR_OWL_AUX_BATCH ? h->max_batch : TSTAR_OWL_AUX_BATCH;
-        const hipError_t e = alloc_lane(L, cap);
-        if (e != hipSuccess) {
-            free_lane(L);
-            set_error(std::string("tstar_owl_score_lane: workspace allocation failed: ") + hipGetErrorString(e));
-            return TSTAR_ERR_HIP;
+    if (lane != 0) {
+        // lane 1: allocated on first use (a one-off, like the resample tables) for forward chunks of min(max_batch, max(TSTAR_OWL_AUX_BATCH, B))
+        // images, and grown when a larger batch arrives (calls on one lane are ordered on one stream: that stream is drained first)
+        int need = B > TSTAR_OWL_AUX_BATCH ? B : TSTAR_OWL_AUX_BATCH;
+        if (need > h->max_batch) need = h->max_batch;
+        if (!L.x || L.cap < need) {
+            if (L.x) { TSTAR_HIP_CHECK(hipStreamSynchronize(s)); free_lane(L); }
+            const hipError_t e = alloc_lane(L, need);
+            if (e != hipSuccess) {
+                free_lane(L);
+                set_error(std::string("tstar_owl_score_lane: workspace allocation failed: ") + hipGetErrorString(e));
+                return TSTAR_ERR_HIP;
+            }
+            TSTAR_HIP_CHECK(hipDeviceSynchronize());      // the zero fill ran on the null stream
         }
-        TSTAR_HIP_CHECK(hipDeviceSynchronize());          // the zero fill ran on the null stream
     }
     int q_uniform = -1;                                   // the common Q when every image uses one set size
     for (int b = 0; b < B; ++b) {

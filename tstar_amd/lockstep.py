@@ -40,7 +40,11 @@ _BESIDE = os.environ.get("TSTAR_SPECULATE_BEHIND") is None
 # TSTAR_NO_VERIFY_AHEAD=1: off (same-session A/Bs).
 _AHEAD = os.environ.get("TSTAR_NO_VERIFY_AHEAD") is None
 _AHEAD_ALWAYS = False   # tests: queue the next batch early even when the running one has already finished (every path, deterministically)
-AUX_IMAGES = 4          # TSTAR_OWL_AUX_BATCH (include/tstar_hip.h): images per forward chunk of lane 1
+AUX_IMAGES = 31         # grid images of one forward that may go to lane 1 (the workspace grows to the batch: include/tstar_hip.h)
+# Alternating lock-step groups (round 6): a group's grid forward runs on the auxiliary stream / lane 1 BESIDE the other group's verification
+# batch instead of behind it, so its cell masks are back -- and its own verification batch queued -- before the detector stream drains
+# (the host's masks -> candidates -> frames step used to leave the chip idle 1-3 ms per group iteration).  TSTAR_GROUP_GRIDS_BEHIND=1: off.
+_GROUP_BESIDE = os.environ.get("TSTAR_GROUP_GRIDS_BEHIND") is None
 
 
 def _side_stream(torch):
@@ -88,6 +92,7 @@ class _Group:
         self.act = []
         self.spec = None               # the NEXT iteration's samples / grid forward, queued speculatively (see speculate())
         self.spec_beside = False       # ... which runs beside the verification batch (auxiliary stream, lane 1), not behind it
+        self.grids_beside = False      # EVERY grid forward of this group beside whatever the detector stream runs (alternating groups)
         self.ahead = None              # ... and its verification batch, queued behind the one in flight (see verify_ahead())
         self.vq = self.masks = None    # the verification batch of THIS iteration (verify_launch()) and the grid's cell masks
         self.solo = False              # one searcher driven through its own slot 0 and its public sample_frames hook
@@ -172,13 +177,20 @@ class _Group:
         self._score_grids(secs_l)
 
     def _score_grids(self, secs_l):
-        """Grid images of the active items' samples and their forward, on the detector stream."""
+        """Grid images of the active items' samples and their forward: on the detector stream, or -- a group that alternates with
+        others -- on the auxiliary stream in the detector's second workspace, beside the other group's verification batch."""
         torch = self.torch
-        grids = [s._device_grid(secs) for s, secs in zip(self.act, secs_l)]
-        self.secs_l, self.grids = secs_l, grids
-        self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(self.act))
-        self.ev_grid = torch.cuda.Event()
-        self.ev_grid.record(self.main)
+        beside = self.grids_beside and self.aux is not None and len(self.act) <= AUX_IMAGES
+        stream = self.aux if beside else self.main
+        with torch.cuda.stream(stream):
+            grids = [s._device_grid(secs) for s, secs in zip(self.act, secs_l)]
+            self.secs_l, self.grids = secs_l, grids
+            if beside:
+                self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(self.act), lane=1)
+            else:
+                self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(self.act))
+            self.ev_grid = torch.cuda.Event()
+            self.ev_grid.record(stream)
 
     def speculate(self):
         """Queue the NEXT iteration's grid forward behind the verification batch that ``middle()`` has just queued, BEFORE its
@@ -407,6 +419,7 @@ def search_lockstep_groups(groups: Sequence[Sequence[TStarSearcher]]) -> List[Li
         gs.append(_Group(g, slot, torch))
         slot += len(g)
     for g in gs:
+        g.grids_beside = _GROUP_BESIDE and len(gs) > 1
         g.install()
     live = [g for g in gs if g.act]
     while live:
