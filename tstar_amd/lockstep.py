@@ -41,10 +41,12 @@ _BESIDE = os.environ.get("TSTAR_SPECULATE_BEHIND") is None
 _AHEAD = os.environ.get("TSTAR_NO_VERIFY_AHEAD") is None
 _AHEAD_ALWAYS = False   # tests: queue the next batch early even when the running one has already finished (every path, deterministically)
 AUX_IMAGES = 31         # grid images of one forward that may go to lane 1 (the workspace grows to the batch: include/tstar_hip.h)
-# Alternating lock-step groups (round 6): a group's grid forward runs on the auxiliary stream / lane 1 BESIDE the other group's verification
-# batch instead of behind it, so its cell masks are back -- and its own verification batch queued -- before the detector stream drains
-# (the host's masks -> candidates -> frames step used to leave the chip idle 1-3 ms per group iteration).  TSTAR_GROUP_GRIDS_BEHIND=1: off.
-_GROUP_BESIDE = os.environ.get("TSTAR_GROUP_GRIDS_BEHIND") is None
+# Alternating lock-step groups, OPT-IN (TSTAR_GROUP_GRIDS_BESIDE=1): a group's grid forward on the auxiliary stream / lane 1 beside the other
+# group's verification batch instead of behind it, so that its cell masks are back -- and its own verification batch queued -- before the
+# detector stream drains (the host's masks -> candidates -> frames step leaves the chip idle 1-3 ms per group iteration).  Measured on the
+# bench's headline: +0.4 % (11.92 -> 11.96 k, 11.88 -> 11.94 k frames/s, same keyframes), while the overlapping launches inflate every
+# per-launch duration the roofline leg times (frac 0.562 -> 0.527, "share of step" above 1): not worth blurring the evidence, so off by default.
+_GROUP_BESIDE = os.environ.get("TSTAR_GROUP_GRIDS_BESIDE") is not None
 
 
 def _side_stream(torch):
