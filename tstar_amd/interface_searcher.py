@@ -374,6 +374,25 @@ class TStarSearcher:
                                                         _lib.stream_ptr()), "tstar_frames_to_grid")
         return grid
 
+    def _device_grid_into(self, d_idx, grid):
+        """``_device_grid`` with the sampled seconds already on the device (int32 [rows * cols]) into a caller-provided uint8
+        [rows * 95, cols * 200, 3] tensor (a slice of a group's stacked grid batch: no per-item index upload, no torch.stack copy)."""
+        rows, cols = self.image_grid_shape
+        if int(d_idx.numel()) != rows * cols:
+            raise ValueError("Frame count does not match grid dimensions")      # :183-184
+        N, H, Wd, _ = self.store.shape
+        _lib.check(self._state.lib.tstar_frames_to_grid(self.store.frames.data_ptr(), N, H, Wd, d_idx.data_ptr(), rows, cols,
+                                                        grid.data_ptr(), int(self.store.fmt == "nv12"), _lib.stream_ptr()),
+                   "tstar_frames_to_grid")
+
+    def _device_resized_into(self, d_idx, out):
+        """``_device_resized`` with the seconds already on the device (int32 [n]) into a caller-provided uint8 [n, h, w, 3] tensor."""
+        N, H, Wd, _ = self.store.shape
+        n, oh, ow, _ = out.shape
+        _lib.check(self._state.lib.tstar_frames_resize(self.store.frames.data_ptr(), N, H, Wd, d_idx.data_ptr(), int(n), int(ow), int(oh),
+                                                       out.data_ptr(), int(self.store.fmt == "nv12"), _lib.stream_ptr()),
+                   "tstar_frames_resize")
+
     def _device_resized(self, secs, out_w: int, out_h: int):
         import torch
         N, H, Wd, _ = self.store.shape

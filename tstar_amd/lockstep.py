@@ -26,7 +26,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 from . import spline_pool
-from .interface_searcher import SAMPLER_WARNING, TStarSearcher
+from .interface_searcher import CELL_H, CELL_W, SAMPLER_WARNING, VERIFY_H, VERIFY_W, TStarSearcher
 
 MAX_GROUP = 63          # TSTAR_OWL_MAX_SETS - 1 query-set slots (include/tstar_hip.h); slot 0 stays the heuristic's own
 
@@ -40,6 +40,7 @@ _BESIDE = os.environ.get("TSTAR_SPECULATE_BEHIND") is None
 # TSTAR_NO_VERIFY_AHEAD=1: off (same-session A/Bs).
 _AHEAD = os.environ.get("TSTAR_NO_VERIFY_AHEAD") is None
 _AHEAD_ALWAYS = False   # tests: queue the next batch early even when the running one has already finished (every path, deterministically)
+_ONE_UPLOAD = os.environ.get("TSTAR_PER_ITEM_UPLOADS") is None   # TSTAR_PER_ITEM_UPLOADS=1: one index upload + torch.stack / cat per item (round 5; A/Bs)
 AUX_IMAGES = 31         # grid images of one forward that may go to lane 1 (the workspace grows to the batch: include/tstar_hip.h)
 # Alternating lock-step groups, OPT-IN (TSTAR_GROUP_GRIDS_BESIDE=1): a group's grid forward on the auxiliary stream / lane 1 beside the other
 # group's verification batch instead of behind it, so that its cell masks are back -- and its own verification batch queued -- before the
@@ -185,14 +186,32 @@ class _Group:
         beside = self.grids_beside and self.aux is not None and len(self.act) <= AUX_IMAGES
         stream = self.aux if beside else self.main
         with torch.cuda.stream(stream):
-            grids = [s._device_grid(secs) for s, secs in zip(self.act, secs_l)]
+            batch, grids = self._grid_batch(self.act, secs_l)
             self.secs_l, self.grids = secs_l, grids
             if beside:
-                self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(self.act), lane=1)
+                self.res = self.h.score_batch(batch, self.rows, self.cols, image_sets=self._sets(self.act), lane=1)
             else:
-                self.res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(self.act))
+                self.res = self.h.score_batch(batch, self.rows, self.cols, image_sets=self._sets(self.act))
             self.ev_grid = torch.cuda.Event()
             self.ev_grid.record(stream)
+
+    def _grid_batch(self, items, secs_l):
+        """The items' grid images as ONE uint8 [n, rows * 95, cols * 200, 3] tensor (and its per-item views): one index upload, every item's
+        gather / resize / tile kernel writes its slice."""
+        torch = self.torch
+        if not _ONE_UPLOAD:
+            grids = [s._device_grid(secs) for s, secs in zip(items, secs_l)]
+            return torch.stack(grids), grids
+        dev = items[0].store.frames.device
+        n = self.n
+        for secs in secs_l:
+            if len(secs) != n:
+                raise ValueError("Frame count does not match grid dimensions")      # interface_searcher.py:183-184
+        d_idx = torch.as_tensor([int(v) for secs in secs_l for v in secs], dtype=torch.int32, device=dev)
+        batch = torch.empty((len(items), self.rows * CELL_H, self.cols * CELL_W, 3), dtype=torch.uint8, device=dev)
+        for i, s in enumerate(items):
+            s._device_grid_into(d_idx[i * n:(i + 1) * n], batch[i])
+        return batch, [batch[i] for i in range(len(items))]
 
     def speculate(self):
         """Queue the NEXT iteration's grid forward behind the verification batch that ``middle()`` has just queued, BEFORE its
@@ -223,12 +242,11 @@ class _Group:
         beside = self.aux is not None and len(items) <= AUX_IMAGES
         stream = self.aux if beside else self.main
         with torch.cuda.stream(stream):
-            for s, secs in zip(items, secs_l):
-                grids.append(s._device_grid(secs))
+            batch, grids = self._grid_batch(items, secs_l)
             if beside:
-                res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(items), lane=1)
+                res = self.h.score_batch(batch, self.rows, self.cols, image_sets=self._sets(items), lane=1)
             else:
-                res = self.h.score_batch(torch.stack(grids), self.rows, self.cols, image_sets=self._sets(items))
+                res = self.h.score_batch(batch, self.rows, self.cols, image_sets=self._sets(items))
             ev = torch.cuda.Event()
             ev.record(stream)
         self.spec = (items, secs_l, grids, res, ev, states, warned)
@@ -267,8 +285,18 @@ class _Group:
         vres = vframes = ev = None
         offs = np.cumsum([0] + [len(c) for c in cand_l])
         if offs[-1] > 0:
-            vframes = torch.cat([s._device_verify_frames([secs_l[i][j] for j in cand_l[i]])
-                                 for i, s in enumerate(act) if cand_l[i]])
+            # ONE index upload and ONE output tensor for the whole group (each item's resize writes its slice): the host's share of the
+            # step between a grid forward's masks and the first kernel of the verification batch is detector idle time
+            if _ONE_UPLOAD:
+                dev = act[0].store.frames.device
+                d_idx = torch.as_tensor([secs_l[i][j] for i in range(len(act)) for j in cand_l[i]], dtype=torch.int32, device=dev)
+                vframes = torch.empty((int(offs[-1]), VERIFY_H, VERIFY_W, 3), dtype=torch.uint8, device=dev)
+                for i, s in enumerate(act):
+                    if cand_l[i]:
+                        s._device_resized_into(d_idx[int(offs[i]):int(offs[i + 1])], vframes[int(offs[i]):int(offs[i + 1])])
+            else:
+                vframes = torch.cat([s._device_verify_frames([secs_l[i][j] for j in cand_l[i]])
+                                     for i, s in enumerate(act) if cand_l[i]])
             sets = None if self.solo else [s._slot for i, s in enumerate(act) for _ in cand_l[i]]
             vres = h.score_batch(vframes, 1, 1, image_sets=sets)
             ev = torch.cuda.Event()
