@@ -452,17 +452,19 @@ def search_lockstep_groups(groups: Sequence[Sequence[TStarSearcher]]) -> List[Li
         g.grids_beside = _GROUP_BESIDE and len(gs) > 1
         g.install()
     live = [g for g in gs if g.act]
+    done = {}
     while live:
         for g in list(live):
             g.end()                    # nothing on the first pass; otherwise the other groups' work has covered the wait
             if not g.act:
                 live.remove(g)
+                done[id(g)] = g.finish()   # its final draws and the keyframes' device -> host copies run under the other groups' detector work
                 continue
             g.begin()
             g.middle()
             if len(live) == 1 and _SPECULATE:
                 g.speculate()          # nothing else would fill the detector between this group's verification and its next grid forward
-    return [g.finish() for g in gs]
+    return [done[id(g)] if id(g) in done else g.finish() for g in gs]
 
 
 def search_solo(searcher: TStarSearcher) -> Tuple[np.ndarray, list]:
