@@ -408,11 +408,32 @@ class TStarSearcher:
         return self._device_resized(secs, VERIFY_W, VERIFY_H)
 
     # ---- distribution ----------------------------------------------------------------------------
-    def store_score_distribution(self):
+    def store_score_distribution(self, _defer_lists: bool = False):
+        """(:207-213) append copies of P / score_distribution / non_visiting_frames to the three histories (lists of lists, like the
+        reference's ``.tolist()``).  ``_defer_lists`` (the fast search loop): the state is read now -- one device -> host copy -- but the
+        three 3.6 k-element numpy -> list conversions (~0.25 ms together) wait for ``_finalize_history()``, which the loop calls once the
+        next iteration's forward is queued: they used to sit between the FITPACK fit and the next draw, on the critical chain of the late
+        iterations.  The histories are complete before anything outside the loop can look at them."""
         st = self._state.read_state()
+        if _defer_lists:
+            self.P_history.append(st[0])
+            self.Score_history.append(st[1])
+            self.non_visiting_history.append(st[2])
+            self._history_pending = True
+            return
         self.P_history.append(st[0].tolist())
         self.Score_history.append(st[1].tolist())
         self.non_visiting_history.append(st[2].tolist())
+
+    def _finalize_history(self):
+        if getattr(self, "_history_pending", False):
+            self._history_pending = False
+            for h in (self.P_history, self.Score_history, self.non_visiting_history):
+                for k in range(len(h) - 1, -1, -1):
+                    if isinstance(h[k], np.ndarray):
+                        h[k] = h[k].tolist()
+                    else:
+                        break
 
     def _update_from_device(self, secs: List[int], d_conf, overlap=None):
         """update_frame_distribution (:276-321) on the device state; d_conf f64 [rows*cols] (cell i <-> sample i).

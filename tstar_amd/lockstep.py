@@ -370,12 +370,17 @@ class _Group:
             for s, P in zip(act, spline_pool.distribution_many(fits, [a.total_frame_num for a in act], s=0.5)):
                 s._state.write(2, P)
             for s in act:
-                s.store_score_distribution()
+                if type(s).store_score_distribution is TStarSearcher.store_score_distribution:
+                    s.store_score_distribution(_defer_lists=True)   # numpy -> list conversions: in end(), off the fit -> next-draw chain
+                else:
+                    s.store_score_distribution()                    # a subclass's own method, with the reference's signature
         vres, vframes, ev, cand_l, offs, _ = self.vq
         self.pending = (vres, vframes, ev, cand_l, offs, names_l)
 
     def end(self):
         """Wait for the verification batch; the sequential ``remaining_targets`` replay and its score overwrites."""
+        for s in self.act:
+            s._finalize_history()                 # (deferred by update(): the next forward is queued by now)
         if self.pending is None:
             if self.spec is not None:             # (defensive: a speculation always follows an update())
                 self._drop_speculation()
@@ -412,6 +417,7 @@ class _Group:
         out = []
         with torch.cuda.stream(self.side):
             for s in self.ss:
+                s._finalize_history()
                 frames, ts = s.pop_frames(video_path=s.video_path, num_samples=s.search_nframes)
                 s.last_time_stamps = list(ts)
                 out.append((frames, ts))
