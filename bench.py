@@ -670,40 +670,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    # one rank per GPU over RCCL; TSTAR_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a
-    # single-GPU box (ranks share the device, collectives go through host tensors)
+    # One rank per GPU.  The path has ONE collective that carries data -- the all-gather of the keyframe rows -- and it goes over RCCL / xGMI
+    # through the library's own communicator (tstar_comm_* / tstar_allgather_i32: the C-ABI entry a non-Python host would use), bootstrapped
+    # over torch.distributed.  torch.distributed itself is only the control plane (barriers, the max-over-ranks of three doubles, the
+    # communicator's unique id) and runs over gloo: no second RCCL communicator in the process, and nothing to tear down and re-create when
+    # RCCL cannot come up -- round 6 found that the old "init nccl, on failure destroy and re-init gloo on another port" fallback HUNG under
+    # torch.distributed.run (its agent store lives on the original port).  If the library's communicator cannot be created (ranks sharing a
+    # GPU: "Duplicate GPU detected"; RCCL not loadable; a hang caught by the watchdog) the rows are gathered over gloo and the line says so
+    # (config.collective_backend / collective_path).  TSTAR_BENCH_BACKEND=gloo skips RCCL outright (N ranks on a 1-GPU box).
     backend = os.environ.get("TSTAR_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            # RCCL over xGMI.  Should the communicator not come up on this node (driver / IPC configuration), the job still
-            # measures: the ranks fall back to gloo for the barriers and the one gather (host tensors), and say so in the
-            # line (config.collective_backend / collective_path) -- the data path has no collective either way.
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-                probe = torch.ones(1, device=torch.device("cuda", local_rank))
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"all_reduce probe returned {probe.item()} instead of {world}")
-            except Exception as e:                      # every rank sees the same failure of a collective bring-up
-                print(f"bench.py[rank {rank}]: RCCL bring-up failed ({e!r}); falling back to gloo", file=sys.stderr)
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
-                backend = "gloo"
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)      # a fresh store
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
-    cdev = "cuda" if backend == "nccl" else "cpu"
+        dist.init_process_group("gloo")
+    cdev = "cpu"
 
     from tstar_amd import _lib
     from tstar_amd.interface_heuristic import OWLInterface
+    from tstar_amd import sharding as _shard
     from tstar_amd.sharding import close_comm, gather_keyframes, interleave_by_item
+    _shard.PREFER_RCCL = backend == "nccl"
     from tstar_amd.video import synthetic_video
     lib = _lib.load()
 
@@ -957,7 +944,10 @@ def main():
                                 "LayerNorm, softmax statistics, epilogues and head tails plain f32"}[args.weights]),
             "data": "synthetic",
             "config": {
-                "collective_backend": (backend if world > 1 else None), "collective_path": collective_path,
+                # the data-path collective that actually ran: "nccl" = ncclAllGather on the library's RCCL communicator, "gloo" = torch.distributed
+                # over gloo (asked for with TSTAR_BENCH_BACKEND=gloo, or the fallback: collective_path says why); the control plane is gloo
+                "collective_backend": (("nccl" if "ncclAllGather" in (collective_path or "") else "gloo") if world > 1 else None),
+                "collective_path": collective_path, "control_plane": ("torch.distributed over gloo" if world > 1 else None),
                 "workload": f"{wl_name}: {wl_what}; {det_name}, grid {g}x{g} = "
                             f"{g * g} frames/iter, search_nframes={args.search_nframes}, threshold 0.6, budget 1000",
                 "workload_kind": workload, "items_total": n_items_total, "population": population,

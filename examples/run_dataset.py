@@ -46,7 +46,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group(os.environ.get("TSTAR_BENCH_BACKEND", "nccl"))
+        # torch.distributed is only the control plane (gloo); the one data collective -- the all-gather of keyframe rows -- goes over RCCL
+        # through the library's own communicator (tstar_amd.sharding), or over gloo with TSTAR_BENCH_BACKEND=gloo / when RCCL cannot come up
+        from tstar_amd import sharding as _shard
+        _shard.PREFER_RCCL = os.environ.get("TSTAR_BENCH_BACKEND", "nccl") == "nccl"
+        dist.init_process_group("gloo")
 
     items = [{"video_path": f"synthetic://n={args.nframes},seed={100 + i}", "targets": QUESTIONS[i % 4][0],
               "cues": QUESTIONS[i % 4][1]} for i in range(args.items)]

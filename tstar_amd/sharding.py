@@ -20,6 +20,7 @@ from typing import Callable, List, Sequence
 _COMM = None            # this process' tstar_comm handle (RCCL communicator created through the C ABI), or False = unavailable
 _COMM_NOTE = ""         # why the library's communicator is not in use (reported in LAST_GATHER_PATH)
 COMM_TIMED_OUT = False  # the watchdog gave up on tstar_comm_create: a thread of this process may still sit inside ncclCommInitRank
+PREFER_RCCL = True      # gather through the library's own RCCL communicator whenever the ranks have GPUs (False / TSTAR_GATHER=gloo: never)
 LAST_GATHER_PATH = None  # which way the last gather_keyframes() went (bench.py reports it as config.collective_path)
 
 
@@ -69,11 +70,12 @@ def _create_with_watchdog(lib, uid: bytes, world: int, rank: int, timeout_s: flo
     return h, ""
 
 
-def _tstar_comm(world: int, rank: int):
+def _tstar_comm(world: int, rank: int, ctl):
     """The library's own RCCL communicator (include/tstar_hip.h: tstar_comm_*), bootstrapped over the already
-    initialised torch.distributed group: rank 0 draws the unique id, the id is broadcast, every rank joins.  Returns
-    the handle, or None when RCCL could not be bound (the caller then gathers through torch.distributed, which is
-    RCCL as well)."""
+    initialised torch.distributed group -- whatever its backend: the control messages (flags, the unique id) travel as ``ctl``-device
+    tensors / pickled objects, so a gloo group is enough and no second RCCL communicator (torch's own) has to exist.  Rank 0 draws the
+    unique id, the id is broadcast, every rank joins.  Returns the handle, or None when RCCL could not be bound or the communicator did
+    not come up on every rank (ranks sharing one GPU: "Duplicate GPU detected"); the caller then gathers through torch.distributed."""
     global _COMM, _COMM_NOTE
     if _COMM is not None:
         return _COMM or None
@@ -94,7 +96,7 @@ def _tstar_comm(world: int, rank: int):
     if not have:
         _COMM_NOTE = lib.tstar_last_error().decode()
         print(f"tstar_amd[rank {rank}]: {_COMM_NOTE}; gathering through torch.distributed", file=sys.stderr)
-    pre = torch.tensor([have], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    pre = torch.tensor([have], dtype=torch.int32, device=ctl)
     dist.all_reduce(pre, op=dist.ReduceOp.MIN)
     if int(pre.item()) != 1:
         _COMM_NOTE = _COMM_NOTE or "RCCL is not loadable on another rank"
@@ -115,7 +117,7 @@ def _tstar_comm(world: int, rank: int):
     # otherwise eat the whole job's time limit.  Every rank then agrees (MIN) on whether the communicator is up.
     h, note = _create_with_watchdog(lib, box[0], world, rank, comm_timeout_s())
     ok = h is not None
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) != 1:
         if ok:
@@ -162,10 +164,12 @@ def gather_keyframes(local_rows: Sequence[Sequence[int]], world: int, pad_to: in
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("gather_keyframes: torch.distributed is not initialised")
-    on_gpu = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    # control plane = the initialised torch.distributed group, whatever its backend (gloo: host tensors; nccl: device tensors); data
+    # path = ONE ncclAllGather on the library's own RCCL communicator whenever the ranks have GPUs, else torch.distributed.all_gather
+    ctl = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    want_rccl = PREFER_RCCL and torch.cuda.is_available() and os.environ.get("TSTAR_GATHER", "rccl") != "gloo"
     k = max([len(r) for r in rows], default=0)
-    shape = torch.tensor([len(rows), k], dtype=torch.int64, device=dev)
+    shape = torch.tensor([len(rows), k], dtype=torch.int64, device=ctl)
     dist.all_reduce(shape, op=dist.ReduceOp.MAX)
     nrow, k = int(shape[0]), int(shape[1])
     if pad_to is not None:
@@ -177,22 +181,24 @@ def gather_keyframes(local_rows: Sequence[Sequence[int]], world: int, pad_to: in
     for i, r in enumerate(rows):
         if r:
             host[1 + i * k:1 + i * k + len(r)] = torch.tensor(r, dtype=torch.int32)
-    buf = host.to(dev)
     n_i32 = 1 + nrow * k
-    comm = _tstar_comm(world, dist.get_rank()) if on_gpu else None
+    comm = _tstar_comm(world, dist.get_rank(), ctl) if want_rccl else None
     if comm is not None:                         # the C-ABI entry a non-Python host would call: ncclAllGather on our stream
         from . import _lib
+        dev = torch.device("cuda", torch.cuda.current_device())
+        buf = host.to(dev)
         flat = torch.empty((world, n_i32), dtype=torch.int32, device=dev)
         _lib.check(_lib.load().tstar_allgather_i32(comm, buf.data_ptr(), flat.data_ptr(), n_i32, _lib.stream_ptr()),
                    "tstar_allgather_i32")
         out = list(flat.cpu())                   # synchronises the stream
         LAST_GATHER_PATH = (f"tstar_allgather_i32: ncclAllGather on the library's own RCCL communicator "
-                            f"({world} ranks, {n_i32} int32 per rank, the caller's stream)")
+                            f"({world} ranks, {n_i32} int32 per rank, the caller's stream; control plane: torch.distributed over {dist.get_backend()})")
     else:
+        buf = host.to(ctl)
         out = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(out, buf)
         LAST_GATHER_PATH = (f"torch.distributed.all_gather over {dist.get_backend()} ({world} ranks)"
-                            + (f"; the library's RCCL communicator was unavailable ({_COMM_NOTE})" if on_gpu else ""))
+                            + (f"; the library's RCCL communicator was unavailable ({_COMM_NOTE})" if want_rccl else ""))
     res: List[List[int]] = []
     for t in out:
         flat_r = t.cpu().numpy()
