@@ -189,6 +189,22 @@ def test_bench_gpus2_typed_as_is_spawns_its_ranks():
         assert two["config"]["collective_backend"] == "nccl" and "ncclAllGather" in two["config"]["collective_path"]
 
 
+@pytest.mark.skipif(torch.cuda.device_count() != 1, reason="the duplicate-GPU failure needs ranks that share one device")
+def test_rccl_that_cannot_come_up_falls_back_to_a_gloo_gather():
+    """Round 6: with the RCCL gather asked for (TSTAR_BENCH_BACKEND=nccl) and two ranks on ONE GPU, ncclCommInitRank fails ("Duplicate GPU
+    detected").  torch.distributed is the gloo control plane only, so nothing has to be torn down: the library's communicator is reported
+    unavailable on every rank, the one gather goes over gloo, and the line comes out with the collective that actually ran.  (The previous
+    torch-level fallback -- destroy the nccl process group, re-init gloo on the next port -- hung under torch.distributed.run.)"""
+    env = dict(_launcher_free_env(), TSTAR_BENCH_BACKEND="nccl")
+    two = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-grid4",
+                       "--no-verify", "--max-batch", "64"], env)
+    c = two["config"]
+    assert two["n_gpus"] == 2 and c["gathered_keyframe_rows"] == 4 and all(len(r) == 8 for r in c["gathered_keyframes"])
+    assert c["collective_backend"] == "gloo" and "RCCL communicator was unavailable" in c["collective_path"] and "ncclCommInitRank" in c["collective_path"]
+    assert c["control_plane"] == "torch.distributed over gloo"
+
+
 def test_bench_gpus8_rehearsal_on_one_gpu():
     """Round 6 (review item 3): the 8-rank launch the driver's SCALE run makes, rehearsed on THIS box -- `python bench.py --gpus 8 ...` typed as
     is starts 8 ranks through torch.distributed.run; with one GPU visible they share the device and gather over gloo (on an 8-GPU node the same
