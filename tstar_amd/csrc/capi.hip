@@ -556,11 +556,11 @@ int tstar_owl_score_lane(tstar_owl* h, int lane, const uint8_t* d_images, int B,
     auto& L = h->lane[lane];
     if (lane != 0) {
         // lane 1: allocated on first use (a one-off, like the resample tables) for forward chunks of min(max_batch, max(TSTAR_OWL_AUX_BATCH, B))
-        // images, and grown when a larger batch arrives (calls on one lane are ordered on one stream: that stream is drained first)
+        // images, and grown when a larger batch arrives (the device is drained first)
         int need = B > TSTAR_OWL_AUX_BATCH ? B : TSTAR_OWL_AUX_BATCH;
         if (need > h->max_batch) need = h->max_batch;
         if (!L.x || L.cap < need) {
-            if (L.x) { TSTAR_HIP_CHECK(hipStreamSynchronize(s)); free_lane(L); }
+            if (L.x) { TSTAR_HIP_CHECK(hipDeviceSynchronize()); free_lane(L); }      // (rare: whichever stream used the smaller workspace last)
             const hipError_t e = alloc_lane(L, need);
             if (e != hipSuccess) {
                 free_lane(L);
