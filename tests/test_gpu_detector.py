@@ -193,8 +193,8 @@ def test_chunked_mixed_query_set_batch_equals_per_image_calls():
 
 @pytest.mark.parametrize("mode", ["f32", "f32x3"])
 def test_second_workspace_lane_same_bits_alone_and_concurrently(mode):
-    """Round 6: ``tstar_owl_score_lane`` -- lane 1 is a second, small activation workspace (forward chunks of 4 images) of the same
-    handle.  A forward in lane 1 gives the bits of the same forward in lane 0 (B = 1 and B = 6 = chunks of 4 + 2 against one chunk),
+    """Round 6: ``tstar_owl_score_lane`` -- lane 1 is a second, small activation workspace of the same handle (4 images, grown to the
+    largest batch it has seen).  A forward in lane 1 gives the bits of the same forward in lane 0 (B = 1, and B = 6 after the workspace grew),
     and a lane-1 grid forward enqueued on ANOTHER stream while a lane-0 verification-size batch is running returns the same bits as
     when each runs alone (the two share no mutable state): what the searcher's speculative next-grid forward relies on."""
     from tstar_amd.interface_heuristic import OWLInterface
