@@ -10,7 +10,7 @@ One "step" = one complete keyframe search (TStarSearcher.search(): iterative sam
 scoring, verification, distribution updates, final K=8 keyframes) over one 3600-frame
 synthetic video that is already resident in HBM -- BASELINE.json configs[1]: "Same single
 video on 1xMI355X, HIP OWL-ViT-B/32 scorer, batch=256 frames/iter" (grid 16x16).  With N > 1
-(torch.distributed, one rank per GPU, RCCL) the workload is BASELINE configs[2]'s shape: every
+(one rank per GPU; torch.distributed over gloo as the control plane, the one data collective over RCCL) the workload is BASELINE configs[2]'s shape: every
 step is its own (video, question) item -- a distinct procedural video, one of four questions --
 item i on rank i % N (weak scaling, no data-path collective), and the final keyframe indices are
 all-gathered once inside the timed region through the library's own RCCL entry point
